@@ -1,0 +1,208 @@
+"""Generates the golden fixtures in this directory by RUNNING THE REFERENCE sampler.
+
+Run only in the build container, where the read-only reference checkout is importable:
+
+    python tests/golden/make_golden.py
+
+The reference's Python never travels: what is committed is this script plus the data it
+emits (inputs, seeds and the reference's outputs).  Weights are not stored; they are
+regenerated from a seed by ``oracle.ref_cpu.make_state_dict`` on any machine.
+
+Version-skew shims (reference pinned transformers 4.47.1, this image has 5.x):
+  * CoDAConfig(..., attn_implementation="eager"), cfg.rope_scaling = None
+  * DLMGenerationConfig.validate accepts the extra arguments transformers 5 passes
+  * an explicit generation_config is always passed to diffusion_generate
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from oracle import ref_cpu  # noqa: E402
+
+from CoDALanguageModel.model_config import CoDAConfig  # noqa: E402
+from CoDALanguageModel.modeling_coda import CoDALanguageModel  # noqa: E402
+from CoDALanguageModel.generation_utils import (  # noqa: E402
+    DLMGenerationConfig, DLMGenerationMixin, sample_tokens, top_p_logits, top_k_logits)
+
+DLMGenerationConfig.validate = lambda self, *a, **k: None
+
+TINY = dict(vocab=512, hidden=64, inter=128, heads=4, kv_heads=2, head_dim=16, layers=2, mask_id=511, pad_id=500,
+            max_pos=4096)
+# smallest shape the HIP kernels accept (head_dim 128, K multiple of 64)
+SMALL = dict(vocab=1024, hidden=256, inter=512, heads=2, kv_heads=1, head_dim=128, layers=2, mask_id=1023, pad_id=1000,
+             max_pos=4096)
+
+
+def ref_model(d: ref_cpu.Dims, sd, dtype):
+    cfg = CoDAConfig(vocab_size=d.vocab, hidden_size=d.hidden, intermediate_size=d.inter,
+                     num_attention_heads=d.heads, num_key_value_heads=d.kv_heads, head_dim=d.head_dim,
+                     num_hidden_layers=d.layers, mask_token_id=d.mask_id, pad_token_id=d.pad_id, bos_token_id=d.pad_id,
+                     eos_token_id=d.pad_id + 1, max_position_embeddings=d.max_pos, attn_implementation="eager")
+    cfg.rope_scaling = None
+    # build under the target default dtype, as from_pretrained(torch_dtype=...) does: parameters
+    # take the dtype, the non-persistent fp32 inv_freq buffer keeps fp32 (a later .to(dtype) would round it)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        m = CoDALanguageModel(cfg)
+    finally:
+        torch.set_default_dtype(old)
+    missing = m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert m.lm_head.weight.dtype == dtype and m.model.rotary_emb.inv_freq.dtype == torch.float32
+    return m.eval()
+
+
+def gen_cfg(d, **kw):
+    return DLMGenerationConfig(mask_token_id=d.mask_id, pad_token_id=d.pad_id, return_dict_in_generate=True,
+                               output_history=True, **kw)
+
+
+def prompts(d, B, P, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, min(d.pad_id, d.mask_id), (B, P), generator=g)
+
+
+def run_e2e(name, dims_kw, dtype, weight_seed, gain, cases, out):
+    d = ref_cpu.Dims(**dims_kw)
+    sd32 = ref_cpu.make_state_dict(d, weight_seed, torch.float32, lm_head_gain=gain, norm_jitter=0.1)
+    sd = {k: v.to(dtype) for k, v in sd32.items()}
+    m = ref_model(d, sd32, dtype)
+    for ci, c in enumerate(cases):
+        B, P, G = c.pop("B"), c.pop("P"), c.pop("G")
+        seed = c.pop("seed", None)
+        ids = prompts(d, B, P, 1000 + ci)
+        if seed is not None:
+            torch.manual_seed(seed)
+        with torch.no_grad():
+            ref = m.diffusion_generate(ids, generation_config=gen_cfg(d, max_new_tokens=G, **c))
+        hist = torch.stack(list(ref.history))
+        # the oracle must reproduce the reference here, bit for bit, on the same seed
+        if seed is not None:
+            torch.manual_seed(seed)
+        tr = ref_cpu.diffusion_generate(sd, d, ids, max_new_tokens=G, **c)
+        same = torch.equal(tr.sequences, ref.sequences) and torch.equal(torch.stack(tr.history), hist)
+        print(f"  {name}[{ci}] {c} oracle==reference: {same}")
+        assert same, "oracle diverges from the reference"
+        key = f"{name}_{ci}"
+        out[key + "_ids"] = ids.numpy()
+        out[key + "_seq"] = ref.sequences.numpy()
+        out[key + "_hist"] = hist.numpy().astype(np.int32)
+        out[key + "_meta"] = np.array(repr(dict(dims=dims_kw, dtype=str(dtype), weight_seed=weight_seed, gain=gain,
+                                                norm_jitter=0.1, B=B, P=P, G=G, seed=seed, **c)))
+    return d, sd, m
+
+
+class Stub(DLMGenerationMixin, torch.nn.Module):
+    """Canned-logits model driving the unmodified reference _sample."""
+
+    def __init__(self, table, mask_id):
+        super().__init__()
+        self.table = table              # [V_in, V] logits emitted for each input token id
+        self.device = torch.device("cpu")
+        self.config = type("C", (), {"max_position_embeddings": 4096})()
+        self.generation_config = DLMGenerationConfig(mask_token_id=mask_id)
+
+    def forward(self, x, attention_mask=None):
+        pos = torch.arange(x.shape[1])[None, :, None]
+        return self.table[x] + 0.37 * torch.sin(pos * 0.91 + torch.arange(self.table.shape[1])[None, None] * 0.13), None
+
+
+def main():
+    out = {}
+    torch.set_num_threads(4)
+
+    # ---- G1: forward logits, fp32, tiny + small
+    for name, kw in (("tiny", TINY), ("small", SMALL)):
+        d = ref_cpu.Dims(**kw)
+        sd = ref_cpu.make_state_dict(d, 7, torch.float32, lm_head_gain=4.0, norm_jitter=0.1)
+        m = ref_model(d, sd, torch.float32)
+        ids = prompts(d, 2, 24, 5)
+        ids[0, 3] = d.mask_id
+        with torch.no_grad():
+            ref_logits, _ = m(ids)
+            # attention_mask is accepted and ignored
+            ref2, _ = m(ids, attention_mask=(ids != ids[0, 0]).float())
+        assert torch.equal(ref_logits, ref2)
+        mine = ref_cpu.forward_logits(sd, d, ids)
+        err = (mine - ref_logits).abs().max().item()
+        print(f"G1 {name}: max |oracle - reference| logits = {err:.3e}")
+        assert err < 1e-5
+        out[f"fwd_{name}_ids"] = ids.numpy()
+        out[f"fwd_{name}_logits"] = ref_logits.numpy()
+        out[f"fwd_{name}_meta"] = np.array(repr(dict(dims=kw, weight_seed=7, gain=4.0, norm_jitter=0.1)))
+
+    # ---- G3/G4: end-to-end, all algs, greedy + stochastic
+    e2e_cases = lambda: [
+        dict(B=2, P=8, G=16, steps=8, alg="entropy"),
+        dict(B=2, P=8, G=16, steps=8, alg="maskgit_plus"),
+        dict(B=2, P=8, G=16, steps=8, alg="topk_margin"),
+        dict(B=3, P=5, G=16, steps=32, alg="entropy"),                      # steps > G: many k=0 steps
+        dict(B=2, P=8, G=16, steps=4, alg="entropy", alg_temp=0.1, seed=11),
+        dict(B=2, P=8, G=16, steps=8, alg="maskgit_plus", temperature=0.7, top_p=0.9, seed=12),
+        dict(B=2, P=8, G=16, steps=8, alg="topk_margin", temperature=0.5, top_k=20, alg_temp=0.2, seed=13),
+        dict(B=2, P=8, G=16, steps=8, alg="origin", seed=14),
+        dict(B=2, P=8, G=16, steps=8, alg="origin", temperature=0.8, seed=15),
+    ]
+    run_e2e("e2e_tiny_f32", TINY, torch.float32, 21, 8.0, e2e_cases(), out)
+    run_e2e("e2e_small_f32", SMALL, torch.float32, 22, 8.0, e2e_cases(), out)
+    run_e2e("e2e_small_bf16", SMALL, torch.bfloat16, 22, 8.0, e2e_cases()[:4], out)
+
+    # ---- G2: sampler-only through the stub model
+    V, mask_id = 2048, 2047
+    g = torch.Generator().manual_seed(3)
+    for scale in (0.05, 1.0, 6.0):
+        table = torch.randn(V, V, generator=g) * scale
+        table[:, mask_id] = -50.0
+        stub = Stub(table, mask_id)
+        for alg, extra in (("entropy", {}), ("maskgit_plus", {}), ("topk_margin", {}),
+                           ("entropy", dict(alg_temp=0.3, temperature=0.6, top_p=0.8))):
+            ids = torch.randint(0, 2000, (3, 6), generator=g)
+            torch.manual_seed(99)
+            gc = DLMGenerationConfig(mask_token_id=mask_id, pad_token_id=2046, return_dict_in_generate=True, output_history=True,
+                                     max_new_tokens=24, steps=6, alg=alg, **extra)
+            with torch.no_grad():
+                ref = stub.diffusion_generate(ids, generation_config=gc)
+            torch.manual_seed(99)
+            args = ref_cpu.SamplerArgs(max_length=30, steps=6, mask_id=mask_id, alg=alg, output_history=True, **extra)
+            tr = ref_cpu.sample_loop(lambda x: stub(x)[0], ids, args)
+            assert torch.equal(tr.sequences, ref.sequences), (scale, alg)
+            tag = f"stub_{scale}_{alg}_{len(extra)}"
+            out[tag + "_ids"] = ids.numpy()
+            out[tag + "_hist"] = torch.stack(list(ref.history)).numpy().astype(np.int32)
+        out[f"stub_{scale}_seed"] = np.array(3)
+    print("stub sampler cases ok")
+
+    # ---- G6: sample_tokens / filters on random logits, every confidence flavour
+    g = torch.Generator().manual_seed(17)
+    logits = torch.randn(12, 1536, generator=g) * 3.0
+    out["st_logits"] = logits.numpy()
+    for nm, kw in (("plain", {}), ("margin", dict(margin_confidence=True)), ("entropy", dict(neg_entropy=True)),
+                   ("topp", dict(top_p=0.9)), ("topk", dict(top_k=50)), ("topp_topk_ent", dict(top_p=0.7, top_k=30, neg_entropy=True))):
+        c, x0 = sample_tokens(logits, temperature=0.0, **kw)
+        kw2 = dict(kw)
+        mine_c, mine_x0 = ref_cpu.sample_tokens(logits, 0.0, kw2.pop("top_p", None), kw2.pop("top_k", None),
+                                                margin=kw2.pop("margin_confidence", False), neg_entropy=kw2.pop("neg_entropy", False))
+        assert torch.equal(c, mine_c) and torch.equal(x0, mine_x0), nm
+        out[f"st_{nm}_conf"] = c.numpy()
+        out[f"st_{nm}_x0"] = x0.numpy()
+    out["st_topp09"] = top_p_logits(logits, 0.9).numpy()
+    out["st_topk50"] = top_k_logits(logits, 50).numpy()
+    # the survey's hand-checked known answer
+    ka = top_p_logits(torch.tensor([[2.0, 1.0, 0.5, 0.0, -1.0]]), 0.9)
+    out["st_known_topp"] = ka.numpy()
+
+    np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
+    sz = os.path.getsize(os.path.join(HERE, "reference_vectors.npz"))
+    print(f"wrote reference_vectors.npz ({sz/1e6:.2f} MB, {len(out)} arrays)")
+
+
+if __name__ == "__main__":
+    main()
