@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CoDA 1.7B masked-diffusion sampler on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full ``model.diffusion_generate`` call on the per-GPU batch of the C2 workload
+(BASELINE.json configs[1]: batch 32, 128-token synthetic prompts, 256 new tokens, 128 denoise
+steps, block_length 32, alg=entropy, greedy, bf16) = 128 full forwards + 128 confidence/selection
+passes.  Weak scaling: every rank runs its own batch of 32 (independent prompts, no per-step
+communication); RCCL is used once per step to gather the completions.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def per_step_flops(B, L, masked_rows):
+    """Algorithmic FLOPs of one denoise step: forward + lm-head over consumed rows."""
+    return B * L * (2_818_572_288 + 229_376 * L) + masked_rows * 622_329_856
+
+
+def window_schedule(bl, steps_b):
+    from coda_amd.generation_utils import fp32_schedule
+    ks, m = [], float(bl)
+    ratios = fp32_schedule(steps_b, 1e-3)
+    for j in range(steps_b):
+        k = int(m) if j == steps_b - 1 else int(torch.tensor(m) * torch.tensor(ratios[j]))
+        ks.append(k)
+        m -= k
+    return ks
+
+
+def cpu_baseline(model, budget_steps):
+    """Times the CPU oracle (the reference algorithm restated in torch, oracle/ref_cpu.py) on the C1 shape
+    (batch 1) for a bounded number of denoise steps on this host's cores."""
+    from oracle import ref_cpu
+    d = ref_cpu.Dims()
+    sd = {k: v.detach().to("cpu", torch.float32) for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(1001)
+    ids = torch.randint(0, 151643, (1, 128), generator=g)
+    with torch.no_grad():
+        ref_cpu.forward_logits(sd, d, ids[:, :16])                         # warm-up
+        t0 = time.perf_counter()
+        ref_cpu.diffusion_generate(sd, d, ids, max_new_tokens=256, steps=128, alg="entropy", block_length=32,
+                                   max_steps=budget_steps)
+        dt = time.perf_counter() - t0
+    s_per_step = dt / budget_steps
+    return dict(value=256.0 / (128 * s_per_step), unit="generated tokens/s", cores=torch.get_num_threads(), kind="port",
+                ms_per_denoise_step=s_per_step * 1e3,
+                sample=f"{budget_steps} of 128 denoise steps of the C1 shape (batch 1, 128+256 tokens, block 32, "
+                       f"entropy, greedy, fp32, random-init 1.7B weights), {dt:.1f} s of CPU work, extrapolated to 128 steps")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="prompts per GPU")
+    ap.add_argument("--prompt", type=int, default=128)
+    ap.add_argument("--new-tokens", type=int, default=256)
+    ap.add_argument("--denoise-steps", type=int, default=128)
+    ap.add_argument("--block-length", type=int, default=32)
+    ap.add_argument("--layers", type=int, default=28, help="debug only; anything but 28 marks the line invalid")
+    ap.add_argument("--cpu-steps", type=int, default=6, help="denoise steps timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)
+
+    from coda_amd import CoDAConfig, CoDALanguageModel
+    from coda_amd.profiling import KernelTimer
+    from coda_amd.dp import gather_completions
+
+    cfg = CoDAConfig(num_hidden_layers=args.layers)
+    torch.manual_seed(1234)                      # same synthetic weights on every rank
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    with torch.device(dev):
+        model = CoDALanguageModel(cfg)
+    torch.set_default_dtype(old)
+    model.eval()
+    with torch.no_grad():
+        model.lm_head.weight.mul_(8.0)           # "peaked" variant: avoids all-tie confidences
+
+    B, P, G, S, bl = args.batch, args.prompt, args.new_tokens, args.denoise_steps, args.block_length
+    L = P + G
+    g = torch.Generator().manual_seed(1002 + rank)
+    ids = torch.randint(0, 151643, (B, P), generator=g).to(dev)
+    gen = dict(max_new_tokens=G, steps=S, alg="entropy", temperature=0.0, block_length=bl, mask_token_id=cfg.mask_token_id)
+
+    eng = model.hip_engine()
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    out = None
+    for _ in range(args.warmup):
+        out = model.diffusion_generate(ids, **gen)
+        gather_completions(out, dist)
+    timer = None if args.no_kernel_timer else KernelTimer(["gate_up", "qkv", "o_proj", "down"], sample_every=8)
+    eng.timer = timer
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model.diffusion_generate(ids, **gen)
+        gathered = gather_completions(out, dist)
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.timer = None
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    masks_left = int((out == cfg.mask_token_id).sum().item())
+    if rank == 0:
+        n_blocks = G // bl
+        ks = window_schedule(bl, S // n_blocks)
+        consumed, m = 0, bl
+        for k in ks:
+            consumed += m
+            m -= k
+        rows_per_gen = consumed * n_blocks * B                      # lm-head rows actually consumed per generate
+        flops_gen = S * per_step_flops(B, L, 0) + rows_per_gen * 622_329_856
+        ms_gen = dt / args.steps * 1e3
+        tok_s = world * B * G * args.steps / dt
+        line = {
+            "metric": "generated tokens/sec (node) @256 tok, 128 steps, block 32; ms per denoise step",
+            "value": tok_s, "unit": "generated tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_gen, "ms_per_denoise_step": ms_gen / S, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic prompts (randint), random-init weights (lm_head x8)",
+            "config": {"workload": "C2: CoDA-1.7B diffusion_generate, batch 32/GPU, prompt 128, 256 new tokens, "
+                                   "steps=128, block_length=32, alg=entropy, greedy", "global_batch": world * B,
+                       "seq_len": L, "parallelism": f"dp{world}", "layers": args.layers,
+                       "valid": args.layers == 28 and (B, P, G, S, bl) == (32, 128, 256, 128, 32)},
+            "masks_left": masks_left,
+            "step_roofline": {"bound": "mfma", "achieved": flops_gen / (ms_gen * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS,
+                              "unit": "TFLOP/s", "frac": flops_gen / (ms_gen * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                              "note": "whole denoise step, algorithmic FLOPs of SURVEY.md 8d (window mode), per GPU"},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            line["kernels"] = summ
+            dom = summ.get("gate_up")
+            if dom:
+                traffic = None
+                tpath = os.path.join(ROOT, "profiles", "traffic.json")
+                if os.path.exists(tpath):
+                    traffic = json.load(open(tpath)).get("gate_up_hbm_bytes_per_launch")
+                line["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel<SWIGLU> (gate|up projection + SiLU*up)",
+                                    "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
+                                    "avg_launch_ms": dom["avg_ms"], "flops_per_launch": dom["flops_per_launch"],
+                                    "launches_timed": dom["launches"]}
+        if world == 1 and args.cpu_steps > 0:
+            line["cpu_baseline"] = cpu_baseline(model, args.cpu_steps)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

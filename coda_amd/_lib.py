@@ -1,0 +1,63 @@
+"""ctypes binding of libcoda_hip.so (the C ABI declared in include/coda_hip.h).
+
+There is no fallback: if the library is missing or a call fails, an exception is raised."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcoda_hip.so")
+
+EPI_PLAIN, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = 0, 1, 2, 3
+ALG_IDS = {"maskgit_plus": 0, "topk_margin": 1, "entropy": 2}
+ERRORS = {-1: "CODA_ERR_SHAPE", -2: "CODA_ERR_ALIGN", -3: "CODA_ERR_LAUNCH", -4: "CODA_ERR_ARG"}
+
+_p, _i, _ll, _f, _ull = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_ulonglong
+
+# name -> (restype, argtypes); must mirror include/coda_hip.h (tests/test_abi.py checks the symbol list)
+SIGNATURES = {
+    "coda_version": (_i, []),
+    "coda_last_error": (ctypes.c_char_p, []),
+    "coda_embed_gather": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "coda_rmsnorm": (_i, [_p, _ll, _p, _p, _ll, _i, _i, _f, _p]),
+    "coda_gemm_bf16": (_i, [_p, _ll, _p, _p, _ll, _p, _ll, _p, _ll, _i, _i, _i, _i, _p]),
+    "coda_qknorm_rope": (_i, [_p, _ll, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "coda_flash_attn_noncausal": (_i, [_p, _ll, _p, _ll, _i, _i, _i, _i, _f, _p]),
+    "coda_build_candidates": (_i, [_p, _i, _i, _i, _i, _ll, _p, _p, _p, _p]),
+    "coda_lmhead_workspace_bytes": (_ll, [_i, _i]),
+    "coda_lmhead_confidence": (_i, [_p, _ll, _p, _p, _p, _i, _p, _ll, _i, _i, _i, _f, _p, _ull, _i, _p, _p, _p, _p]),
+    "coda_confidence_from_logits": (_i, [_p, _ll, _i, _i, _i, _p, _p, _i, _f, _f, _i, _p, _ull, _i, _p, _p, _p]),
+    "coda_select_unmask": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _ll, _f, _i, _f, _p, _p, _p]),
+    "coda_origin_transfer": (_i, [_p, _p, _p, _p, _i, _p, _f, _p]),
+}
+
+_lib = None
+
+
+class CodaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library once; raises CodaHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CodaHipError(
+            f"{LIB_PATH} not found: build it with `make -C coda_amd/csrc` (or __graft_entry__.build()). "
+            "coda_amd has no CPU or PyTorch fallback for the sampler path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Calls an int-returning entry point and raises on a negative return code."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        detail = lib.coda_last_error().decode() if rc == -3 else ""
+        raise CodaHipError(f"{name} failed: {ERRORS.get(rc, rc)} {detail}")

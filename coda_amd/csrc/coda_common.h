@@ -1,0 +1,51 @@
+// Shared device helpers for the CoDA MI355X (gfx950 / CDNA4) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+#define CODA_LDS __attribute__((address_space(3)))
+#define CODA_GLOBAL __attribute__((address_space(1)))
+
+#include "coda_hip.h"   // public C ABI (include/): error codes, enums, prototypes
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned int)b) << 16); }
+
+// round-to-nearest-even f32 -> bf16 bits (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950, NaN-safe)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, h);
+}
+
+// value of f after a round trip through bf16 (emulates an op whose output dtype is bf16)
+__device__ __forceinline__ float round_bf16(float f) { return bf16_bits_to_f32(f32_to_bf16_bits(f)); }
+
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    return (unsigned int)f32_to_bf16_bits(lo) | ((unsigned int)f32_to_bf16_bits(hi) << 16);
+}
+
+// 16-byte asynchronous global -> LDS copy.  The LDS destination is wave-uniform base + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const CODA_GLOBAL void*)gsrc, (CODA_LDS void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Bijective XCD-aware remap of a linear workgroup id: workgroups that share an XCD (id % 8 equal
+// under round-robin dispatch) receive one contiguous chunk of the logical tile order.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}

@@ -1,0 +1,215 @@
+// Non-causal, mask-free GQA flash attention forward for head_dim 128 on CDNA4 MFMA.
+// Replaces attention.py:12-90 of the reference (repeat_kv + SDPA(is_causal=False), no mask: SURVEY F3).
+//
+// Work split: one workgroup = 4 waves = 128 queries of one (batch, q head); each wave owns 32
+// queries.  K/V tiles of 64 keys are streamed through a double-buffered LDS ring by LDS-DMA.
+//
+// MFMA orientation (v_mfma_f32_32x32x16_bf16 everywhere):
+//   S^T[key][query] = K Q^T   A = K rows from LDS (ds_read_b128), B = Q^T held in registers.
+//                             A lane then holds one query (lane&31) and 16 of the tile's keys per
+//                             32-key sub-tile, so the softmax row reduction is in-lane + one
+//                             cross-half shuffle, and the accumulator registers are directly the
+//                             B operand of the second product (no LDS round trip for P).
+//   O^T[d][query]  += V^T P^T A = V^T read with ds_read_b64_tr_b16 (hardware transpose),
+//                             B = bf16(P) from the S^T accumulator.  O^T keeps the query on the
+//                             lane, so the online-softmax rescale is a per-lane scalar.
+// LDS image for both K and V tiles: 64 rows x 256 B, 16-B chunk ch of row r stored at chunk
+// ch ^ (((r&3)<<2) | ((r>>2)&3)): conflict-free for the b128 row reads and the transposed reads.
+#include "coda_abi_internal.h"
+
+namespace {
+
+constexpr int QB = 128;      // queries per workgroup
+constexpr int KB = 64;       // keys per tile
+constexpr int TILE = KB * 256;                 // 16 KiB
+constexpr int ATTN_LDS = 4 * TILE;             // K[2] + V[2]
+
+struct AttnArgs {
+    const char* qkv; long long ld_b;
+    char* out; long long ldo_b;
+    int B, L, n_q, n_kv;
+    float scale_log2e;
+};
+
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int qblk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int kvh = head / (a.n_q / a.n_kv);
+    const int L = a.L;
+    const char* base = a.qkv + (size_t)b * L * a.ld_b;
+    const char* kbase = base + (size_t)(a.n_q + kvh) * 256;
+    const char* vbase = base + (size_t)(a.n_q + a.n_kv + kvh) * 256;
+
+    // ---- Q^T fragments: lane (query c, half h), k-step ks: Q[q][16 ks + 8 h .. +7]
+    const int q_row = qblk * QB + wave * 32 + c;
+    const int q_ld = min(q_row, L - 1);
+    bf16x8_t qf[8];
+    {
+        const char* qp = base + (size_t)q_ld * a.ld_b + (size_t)head * 256 + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8_t*)(qp + ks * 32);
+    }
+
+    // ---- LDS-DMA source addressing: instruction i of this wave fills rows (i*4 + wave)*4 .. +3
+    const int dma_r = lane >> 4;                                   // row within the 4-row piece
+    const int dma_src_chunk = (lane & 15) ^ ((dma_r << 2) | wave); // swz(row) for row = (i*4+wave)*4 + dma_r
+    auto stage = [&](int t, int buf) {
+        char* kd = lds + buf * TILE;
+        char* vd = lds + (2 + buf) * TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (i * 4 + wave) * 4 + dma_r;
+            const int key = min(t * KB + r, L - 1);
+            const size_t go = (size_t)key * a.ld_b + dma_src_chunk * 16;
+            glds16(kbase + go, kd + (i * 4 + wave) * 1024);
+            glds16(vbase + go, vd + (i * 4 + wave) * 1024);
+        }
+    };
+
+    f32x16_t oacc[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    // per-lane LDS read offsets
+    //  K row read (A operand of S^T): row = 32*kt2 + c, chunk = 2*ks + h
+    //  V transposed read: lane i16 = lane&15 -> (q = i16>>2, p = i16&3); row = key0 + q,
+    //  chunk = 4*db + 2*((lane>>4)&1) + (p>>1), byte 8*(p&1)
+    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+    const int v_chunk0 = 2 * ((lane >> 4) & 1) + (tp >> 1);
+    const int v_byte = 8 * (tp & 1);
+
+    const int nt = (L + KB - 1) / KB;
+    stage(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+        const char* kt = lds + (t & 1) * TILE;
+        const char* vt = lds + (2 + (t & 1)) * TILE;
+
+        // ---- S^T = K Q^T : two 32-key sub-tiles
+        f32x16_t s[2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[k2][i] = 0.f;
+            const int row = 32 * k2 + c;
+            const char* rp = kt + row * 256;
+            const int sw = swz(row);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8_t kf = *(const bf16x8_t*)(rp + (((2 * ks + h) ^ sw) << 4));
+                s[k2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[k2], 0, 0, 0);
+            }
+        }
+        // ---- mask keys beyond L (last tile only)
+        if ((t + 1) * KB > L) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = t * KB + 32 * k2 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= L) s[k2][i] = -1e30f;
+                }
+        }
+        // ---- online softmax (per query = per lane column; the two halves hold disjoint keys)
+        float mx = s[0][0];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[k2][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f((m_run - m_new) * a.scale_log2e);
+        const float mb = m_new * a.scale_log2e;
+        float psum = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = exp2f(s[k2][i] * a.scale_log2e - mb);
+                s[k2][i] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+
+        // ---- O^T += V^T P^T : 4 k-steps of 16 keys, 4 d-blocks of 32
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int k2 = st >> 1, r0 = 8 * (st & 1);
+            bf16x8_t pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[k2][r0 + j];
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                s16x4_t lo4, hi4;
+                {
+                    const int row = 32 * k2 + 16 * (st & 1) + 4 * h + tq;            // jj = 0
+                    const int off = row * 256 + (((4 * db + v_chunk0) ^ swz(row)) << 4) + v_byte;
+                    lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((CODA_LDS s16x4_t*)(vt + off));
+                }
+                {
+                    const int row = 32 * k2 + 16 * (st & 1) + 8 + 4 * h + tq;        // jj = 1
+                    const int off = row * 256 + (((4 * db + v_chunk0) ^ swz(row)) << 4) + v_byte;
+                    hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((CODA_LDS s16x4_t*)(vt + off));
+                }
+                typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+                const s16x8_t v8 = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, v8), pf, oacc[db], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: normalise, store bf16.  reg i of d-block db: d = 32 db + (i&3) + 8 (i>>2) + 4 h
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row < L) {
+        char* op = a.out + ((size_t)b * L + q_row) * a.ldo_b + (size_t)head * 256;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = 32 * db + 8 * g + 4 * h;
+                u32x2_t v = {pack_bf16x2(oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv),
+                             pack_bf16x2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv)};
+                *(u32x2_t*)(op + d * 2) = v;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void* out, long long ld_out, int B, int L,
+                                         int n_q, int n_kv, float scale, void* stream) {
+    if (B <= 0 || L <= 0 || n_q <= 0 || n_kv <= 0 || n_q % n_kv) return CODA_ERR_SHAPE;
+    if (ld_qkv < (long long)(n_q + 2 * n_kv) * 128 || ld_out < (long long)n_q * 128) return CODA_ERR_SHAPE;
+    if (B > 65535 || n_q > 65535) return CODA_ERR_SHAPE;
+    if (!qkv || !out) return CODA_ERR_ARG;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 7) || (ld_qkv * 2) % 16 || (ld_out * 2) % 8) return CODA_ERR_ALIGN;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)flash_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS) != hipSuccess)
+            return CODA_ERR_LAUNCH;
+        attr_done = true;
+    }
+    AttnArgs a;
+    a.qkv = (const char*)qkv; a.ld_b = ld_qkv * 2;
+    a.out = (char*)out; a.ldo_b = ld_out * 2;
+    a.B = B; a.L = L; a.n_q = n_q; a.n_kv = n_kv;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(flash_attn_kernel, dim3((L + QB - 1) / QB, n_q, B), dim3(256), ATTN_LDS, (hipStream_t)stream, a);
+    CODA_CHECK_LAUNCH("flash_attn");
+    return CODA_OK;
+}

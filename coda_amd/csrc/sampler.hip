@@ -1,0 +1,190 @@
+// Integer / selection side of one denoise step: candidate list, schedule, top-k selection and the
+// in-place token scatter.  Everything stays on the device (the reference needs >= 3 host syncs
+// per step: nonzero() behind the boolean gather, int(k), torch.any).
+#include "coda_abi_internal.h"
+
+// ------------------------------------------------------------------ candidate list
+// generation_utils.py:455-462.  Single workgroup (ordered compaction; the list is KB-sized).
+__global__ __launch_bounds__(1024) void build_candidates_kernel(const long long* __restrict__ x, int B, int L, int lo, int hi,
+                                                                long long mask_id, int* __restrict__ src_rows,
+                                                                int* __restrict__ dst_pos, int* __restrict__ count) {
+    __shared__ int wave_tot[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nw = hi - lo;
+    const long long total = (long long)B * nw;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (long long start = 0; start < total; start += 1024) {
+        const long long e = start + tid;
+        int b = 0, p = 0;
+        bool flag = false;
+        if (e < total) {
+            b = (int)(e / nw);
+            p = lo + (int)(e % nw);
+            flag = x[(size_t)b * L + p] == mask_id;
+        }
+        const unsigned long long bal = __ballot(flag);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (flag) {
+            src_rows[off + pre] = b * L + (p > 0 ? p - 1 : 0);
+            dst_pos[off + pre] = b * L + p;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int s = 0;
+            for (int w = 0; w < 16; ++w) s += wave_tot[w];
+            base_s += s;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) count[0] = base_s;
+}
+
+extern "C" int coda_build_candidates(const long long* x, int B, int L, int win_lo, int win_hi, long long mask_id,
+                                     int* src_rows, int* dst_pos, int* count, void* stream) {
+    if (B <= 0 || L <= 0 || win_lo < 0 || win_hi > L || win_lo >= win_hi) return CODA_ERR_SHAPE;
+    if ((long long)B * L > 2147483647LL) return CODA_ERR_SHAPE;
+    if (!x || !src_rows || !dst_pos || !count) return CODA_ERR_ARG;
+    hipLaunchKernelGGL(build_candidates_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, B, L, win_lo, win_hi, mask_id,
+                       src_rows, dst_pos, count);
+    CODA_CHECK_LAUNCH("build_candidates");
+    return CODA_OK;
+}
+
+// ------------------------------------------------------------------ schedule + top-k + scatter
+// generation_utils.py:507-538.  One workgroup per sequence.  The candidates of the row are
+// compacted into LDS in position order, keyed, then ranked by an all-pairs count (each wave
+// broadcasts key j while every lane holds its own candidate): exact, deterministic, ties go to
+// the lowest position.  Window sizes are <= a few thousand, so the O(n^2/256) ranking is us-scale.
+__global__ __launch_bounds__(256) void select_unmask_kernel(long long* __restrict__ x, const float* __restrict__ conf,
+                                                            const long long* __restrict__ x0, const int* __restrict__ count,
+                                                            int B, int L, int lo, int hi, long long mask_id, float ratio,
+                                                            int take_all, float alg_temp, const float* __restrict__ noise,
+                                                            int* __restrict__ k_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nw = hi - lo;
+    float* key = (float*)smem;                 // [nw]
+    int* cpos = (int*)(smem + (size_t)nw * 4); // [nw]
+    __shared__ int wave_tot[4];
+    __shared__ float red[4];
+    __shared__ int n_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+
+    // k exactly as the reference: fp32 (sum / B) * (1 - s/t), truncated toward zero
+    const float n_mask = __fdiv_rn((float)count[0], (float)B);
+    const int k = take_all ? (int)n_mask : (int)__fmul_rn(n_mask, ratio);
+    if (b == 0 && tid == 0 && k_out) k_out[0] = k;
+    if (k <= 0) return;
+
+    // ordered compaction of this row's masked window positions
+    if (tid == 0) n_s = 0;
+    __syncthreads();
+    for (int start = 0; start < nw; start += 256) {
+        const int e = start + tid;
+        const int p = lo + e;
+        const bool flag = e < nw && x[(size_t)b * L + p] == mask_id;
+        const unsigned long long bal = __ballot(flag);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(bal);
+        __syncthreads();
+        int off = n_s;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (flag) {
+            cpos[off + pre] = p;
+            key[off + pre] = conf[(size_t)b * L + p];
+        }
+        __syncthreads();
+        if (tid == 0) n_s += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    const int n = n_s;
+    if (n == 0) return;
+
+    if (alg_temp > 0.f) {
+        // key = softmax(conf / alg_temp) / Exp(1) noise  (== multinomial without replacement)
+        float mx = -INFINITY;
+        for (int i = tid; i < n; i += 256) mx = fmaxf(mx, key[i] / alg_temp);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0) red[wave] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        float z = 0.f;
+        for (int i = tid; i < n; i += 256) z += expf(key[i] / alg_temp - mx);
+        z = wave_sum(z);
+        if (lane == 0) red[wave] = z;
+        __syncthreads();
+        z = red[0] + red[1] + red[2] + red[3];
+        for (int i = tid; i < n; i += 256) {
+            const float pr = expf(key[i] / alg_temp - mx) / z;
+            key[i] = pr / noise[(size_t)b * L + cpos[i]];
+        }
+        __syncthreads();
+    }
+
+    for (int i = tid; i < n; i += 256) {
+        bool take = true;
+        if (k < n) {
+            const float ki = key[i];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) {
+                const float kj = key[j];
+                rank += (kj > ki) || (kj == ki && j < i);
+            }
+            take = rank < k;
+        }
+        if (take) {
+            const size_t at = (size_t)b * L + cpos[i];
+            x[at] = x0[at];
+        }
+    }
+}
+
+extern "C" int coda_select_unmask(long long* x, const float* conf, const long long* x0, const int* count, int B, int L,
+                                  int win_lo, int win_hi, long long mask_id, float ratio, int take_all, float alg_temp,
+                                  const float* noise, int* k_out, void* stream) {
+    if (B <= 0 || L <= 0 || win_lo < 0 || win_hi > L || win_lo >= win_hi) return CODA_ERR_SHAPE;
+    if (win_hi - win_lo > 16384) return CODA_ERR_SHAPE;      // LDS budget: 8 B per window position
+    if (!x || !conf || !x0 || !count) return CODA_ERR_ARG;
+    if (alg_temp > 0.f && !noise) return CODA_ERR_ARG;
+    const size_t lds = (size_t)(win_hi - win_lo) * 8;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)select_unmask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8) != hipSuccess)
+            return CODA_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(select_unmask_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, x, conf, x0, count, B, L, win_lo,
+                       win_hi, mask_id, ratio, take_all, alg_temp, noise, k_out);
+    CODA_CHECK_LAUNCH("select_unmask");
+    return CODA_OK;
+}
+
+// ------------------------------------------------------------------ `origin` transfer
+// generation_utils.py:466-483
+__global__ void origin_transfer_kernel(long long* __restrict__ x, const long long* __restrict__ x0, const int* __restrict__ dst_pos,
+                                       const int* __restrict__ count, const float* __restrict__ u, float p_transfer) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count[0]) return;
+    if (u[i] < p_transfer) {
+        const int at = dst_pos[i];
+        x[at] = x0[at];
+    }
+}
+
+extern "C" int coda_origin_transfer(long long* x, const long long* x0, const int* dst_pos, const int* count, int max_rows,
+                                    const float* u, float p_transfer, void* stream) {
+    if (max_rows <= 0) return CODA_ERR_SHAPE;
+    if (!x || !x0 || !dst_pos || !count || !u) return CODA_ERR_ARG;
+    hipLaunchKernelGGL(origin_transfer_kernel, dim3((max_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, x0, dst_pos,
+                       count, u, p_transfer);
+    CODA_CHECK_LAUNCH("origin_transfer");
+    return CODA_OK;
+}

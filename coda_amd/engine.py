@@ -1,0 +1,196 @@
+"""Host side of the MI355X sampler engine: packed weights, HBM workspaces and the kernel launch
+sequence of one decoder forward / one denoise step.  PyTorch is used for device memory and
+streams only; all arithmetic is done by libcoda_hip.so (see include/coda_hip.h).
+
+HBM layout (bf16 unless noted; T = B*L tokens, row-major, all buffers resident for the whole
+generation - nothing is re-allocated inside the denoise loop):
+  weights   embed [V,H]; per layer  wqkv [(n_q+2 n_kv)*128, H] (q|k|v rows concatenated),
+            wo [H, n_q*128], wgu [2I, H] (gate/up interleaved in blocks of 16 rows so that one
+            MFMA accumulator pair holds gate and up of the same feature), wd [H, I], norm vectors;
+            final norm [H]; lm_head [V,H]
+  state     h [T,H] residual stream, a [T,H] normed input, qkv [T,(n_q+2 n_kv)*128],
+            ao [T,n_q*128] attention output, mlp [T,I], hn [T,H] final-normed hidden
+  sampler   src_rows/dst_pos int32 [B*W], count int32[1], conf fp32 [T], x0 int64 [T],
+            lm-head partial-statistics workspace (<= 4.2 MB), k int32[1]
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """[I,H],[I,H] -> [2I,H] with rows 32j..32j+15 = gate[16j..], 32j+16..32j+31 = up[16j..]."""
+    I, H = gate.shape
+    assert I % 16 == 0
+    return torch.stack((gate.view(I // 16, 16, H), up.view(I // 16, 16, H)), dim=1).reshape(2 * I, H).contiguous()
+
+
+class HipEngine:
+    """One engine per model replica (per GPU)."""
+
+    def __init__(self, cfg, state: Dict[str, torch.Tensor], device: torch.device):
+        if device.type != "cuda":
+            raise _lib.CodaHipError("the CoDA sampler engine runs on an MI355X only (model is on %s)" % device)
+        _lib.load()
+        self.device = device
+        self.V, self.H, self.I = cfg.vocab_size, cfg.hidden_size, cfg.intermediate_size
+        self.n_q, self.n_kv, self.d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        self.layers = cfg.num_hidden_layers
+        self.eps = float(cfg.rms_norm_eps)
+        self.theta = cfg.rope_theta
+        if self.d != 128:
+            raise _lib.CodaHipError("HIP kernels are specialised for head_dim 128")
+        if self.n_q * self.d != self.H and False:
+            pass
+        if self.H % 64 or self.I % 64 or (self.n_q * self.d) % 64:
+            raise _lib.CodaHipError("hidden/intermediate sizes must be multiples of 64")
+        self.qkv_dim = (self.n_q + 2 * self.n_kv) * self.d
+        bf = torch.bfloat16
+
+        def w(key):
+            return state[key].detach().to(device=device, dtype=bf).contiguous()
+
+        self.embed = w("model.embed_tokens.weight")
+        self.lm_head = w("lm_head.weight")
+        self.final_norm = w("model.norm.weight")
+        self.lw = []
+        for i in range(self.layers):
+            p = f"model.layers.{i}."
+            self.lw.append(dict(
+                n_in=w(p + "input_layernorm.weight"), n_post=w(p + "post_attention_layernorm.weight"),
+                qn=w(p + "self_attn.q_norm.weight"), kn=w(p + "self_attn.k_norm.weight"),
+                wqkv=torch.cat([w(p + "self_attn.q_proj.weight"), w(p + "self_attn.k_proj.weight"),
+                                w(p + "self_attn.v_proj.weight")], dim=0).contiguous(),
+                wo=w(p + "self_attn.o_proj.weight"),
+                wgu=interleave_gate_up(w(p + "mlp.gate_proj.weight"), w(p + "mlp.up_proj.weight")),
+                wd=w(p + "mlp.down_proj.weight")))
+        self._shape = None
+        self._rope = {}
+        self.timer = None          # optional KernelTimer (bench.py)
+
+    # ------------------------------------------------------------------ workspaces
+    def _ensure(self, B: int, L: int):
+        if self._shape == (B, L):
+            return
+        T, dev, bf = B * L, self.device, torch.bfloat16
+        self.h = torch.empty(T, self.H, device=dev, dtype=bf)
+        self.a = torch.empty(T, self.H, device=dev, dtype=bf)
+        self.qkv = torch.empty(T, self.qkv_dim, device=dev, dtype=bf)
+        self.ao = torch.empty(T, self.n_q * self.d, device=dev, dtype=bf)
+        self.mlp = torch.empty(T, self.I, device=dev, dtype=bf)
+        self.hn = torch.empty(T, self.H, device=dev, dtype=bf)
+        self.src_rows = torch.zeros(T, device=dev, dtype=torch.int32)
+        self.dst_pos = torch.zeros(T, device=dev, dtype=torch.int32)
+        self.count = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.k_out = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.conf = torch.zeros(T, device=dev, dtype=torch.float32)
+        self.x0 = torch.zeros(T, device=dev, dtype=torch.int64)
+        ws = _lib.load().coda_lmhead_workspace_bytes(T, self.V)
+        self.lm_ws = torch.empty(ws, device=dev, dtype=torch.uint8)
+        if L not in self._rope:
+            # cos/sin exactly as the reference builds them: fp32 on the host, then cast to bf16
+            inv = 1.0 / (self.theta ** (torch.arange(0, self.d, 2, dtype=torch.int64).float() / self.d))
+            ang = torch.arange(L).float()[:, None] * inv[None, :]
+            emb = torch.cat((ang, ang), dim=-1)
+            self._rope = {L: (emb.cos().to(bf).to(dev).contiguous(), emb.sin().to(bf).to(dev).contiguous())}
+        self._shape = (B, L)
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _gemm(self, name, X, W, C, epi, R=None, rows=None, M=None):
+        M = X.shape[0] if M is None else M
+        N, K = W.shape
+        ldc = C.stride(0)
+        t = self.timer
+        if t is not None:
+            t.begin(name, 2.0 * M * N * K)
+        _lib.call("coda_gemm_bf16", _ptr(X), X.stride(0), _ptr(rows), _ptr(W), W.stride(0), _ptr(C), ldc,
+                  _ptr(R), 0 if R is None else R.stride(0), M, N, K, epi, self._stream())
+        if t is not None:
+            t.end(name)
+
+    # ------------------------------------------------------------------ decoder forward
+    @torch.no_grad()
+    def forward_hidden(self, ids: torch.Tensor) -> torch.Tensor:
+        """ids int64 [B,L] on the device -> final-normed hidden states bf16 [B*L, H] (engine-owned)."""
+        B, L = ids.shape
+        self._ensure(B, L)
+        T, s = B * L, self._stream()
+        cos, sin = self._rope[L]
+        ids = ids.contiguous()
+        _lib.call("coda_embed_gather", _ptr(ids), _ptr(self.embed), _ptr(self.h), T, self.V, self.H, s)
+        scale = 1.0 / math.sqrt(self.d)
+        for lw in self.lw:
+            _lib.call("coda_rmsnorm", _ptr(self.h), self.H, _ptr(lw["n_in"]), _ptr(self.a), self.H, T, self.H, self.eps, s)
+            self._gemm("qkv", self.a, lw["wqkv"], self.qkv, _lib.EPI_PLAIN)
+            _lib.call("coda_qknorm_rope", _ptr(self.qkv), self.qkv_dim, _ptr(lw["qn"]), _ptr(lw["kn"]), _ptr(cos),
+                      _ptr(sin), T, L, self.n_q, self.n_kv, self.eps, s)
+            _lib.call("coda_flash_attn_noncausal", _ptr(self.qkv), self.qkv_dim, _ptr(self.ao), self.n_q * self.d, B, L,
+                      self.n_q, self.n_kv, scale, s)
+            self._gemm("o_proj", self.ao, lw["wo"], self.h, _lib.EPI_RESIDUAL, R=self.h)
+            _lib.call("coda_rmsnorm", _ptr(self.h), self.H, _ptr(lw["n_post"]), _ptr(self.a), self.H, T, self.H, self.eps, s)
+            self._gemm("gate_up", self.a, lw["wgu"], self.mlp, _lib.EPI_SWIGLU)
+            self._gemm("down", self.mlp, lw["wd"], self.h, _lib.EPI_RESIDUAL, R=self.h)
+        _lib.call("coda_rmsnorm", _ptr(self.h), self.H, _ptr(self.final_norm), _ptr(self.hn), self.H, T, self.H, self.eps, s)
+        return self.hn
+
+    @torch.no_grad()
+    def logits(self, ids: torch.Tensor) -> torch.Tensor:
+        """Unshifted logits bf16 [B, L, V] (what model(x) returns in eval mode)."""
+        B, L = ids.shape
+        hn = self.forward_hidden(ids)
+        out = torch.empty(B * L, self.V, device=self.device, dtype=torch.bfloat16)
+        self._gemm("lm_head_full", hn, self.lm_head, out, _lib.EPI_PLAIN)
+        return out.view(B, L, self.V)
+
+    # ------------------------------------------------------------------ sampler steps
+    def build_candidates(self, x: torch.Tensor, lo: int, hi: int):
+        B, L = x.shape
+        _lib.call("coda_build_candidates", _ptr(x), B, L, lo, hi, self._mask_id, _ptr(self.src_rows), _ptr(self.dst_pos),
+                  _ptr(self.count), self._stream())
+
+    def set_mask_id(self, mask_id: int):
+        self._mask_id = int(mask_id)
+
+    def lmhead_confidence(self, max_rows: int, alg: int, temperature: float, noise, seed: int, round_conf: bool):
+        _lib.call("coda_lmhead_confidence", _ptr(self.hn), self.H, _ptr(self.src_rows), _ptr(self.dst_pos), _ptr(self.count),
+                  max_rows, _ptr(self.lm_head), self.H, self.V, self.H, alg, float(temperature), _ptr(noise), seed,
+                  int(round_conf), _ptr(self.conf), _ptr(self.x0), _ptr(self.lm_ws), self._stream())
+
+    def candidate_logits(self, max_rows: int) -> torch.Tensor:
+        """Materialises bf16 logits [max_rows, V] of the candidate rows (top-p / top-k path)."""
+        out = torch.empty(max_rows, self.V, device=self.device, dtype=torch.bfloat16)
+        self._gemm("lm_head_rows", self.hn, self.lm_head, out, _lib.EPI_PLAIN, rows=self.src_rows, M=max_rows)
+        return out
+
+    def confidence_from_logits(self, logits: torch.Tensor, alg: int, temperature: float, top_p, top_k, noise, seed: int,
+                               round_conf: bool, use_count: bool = True, scatter: bool = True,
+                               conf: Optional[torch.Tensor] = None, x0: Optional[torch.Tensor] = None):
+        N, V = logits.shape
+        is_bf16 = 1 if logits.dtype == torch.bfloat16 else 0
+        if not is_bf16 and logits.dtype != torch.float32:
+            raise _lib.CodaHipError("logits must be bf16 or fp32")
+        _lib.call("coda_confidence_from_logits", _ptr(logits), logits.stride(0), is_bf16, N, V,
+                  _ptr(self.count) if use_count else None, _ptr(self.dst_pos) if scatter else None, alg, float(temperature),
+                  float(top_p) if top_p is not None else 0.0, int(top_k) if top_k is not None else 0, _ptr(noise), seed,
+                  int(round_conf), _ptr(self.conf if conf is None else conf), _ptr(self.x0 if x0 is None else x0),
+                  self._stream())
+
+    def select_unmask(self, x: torch.Tensor, lo: int, hi: int, ratio: float, take_all: bool, alg_temp: float, noise):
+        B, L = x.shape
+        _lib.call("coda_select_unmask", _ptr(x), _ptr(self.conf), _ptr(self.x0), _ptr(self.count), B, L, lo, hi, self._mask_id,
+                  float(ratio), int(take_all), float(alg_temp), _ptr(noise), _ptr(self.k_out), self._stream())
+
+    def origin_transfer(self, x: torch.Tensor, max_rows: int, u: torch.Tensor, p_transfer: float):
+        _lib.call("coda_origin_transfer", _ptr(x), _ptr(self.x0), _ptr(self.dst_pos), _ptr(self.count), max_rows, _ptr(u),
+                  float(p_transfer), self._stream())

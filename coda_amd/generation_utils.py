@@ -1,0 +1,288 @@
+"""Masked-diffusion generation API: ``model.diffusion_generate(...)``.
+
+Drop-in for the reference's DLMGenerationMixin (CoDALanguageModel/generation_utils.py:103-552):
+same call signature, same DLMGenerationConfig fields and defaults, same errors and warnings,
+same outputs - but the denoise loop runs on hand-written CDNA4 kernels (coda_amd/csrc) and stays
+device-resident: no host sync per step, no [B,L,V] logits unless a hook asks for them.
+
+Build-defined additions (all optional, defaults reproduce the reference):
+  block_length   windowed unmasking; None or == max_new_tokens -> reference
+  round_conf_to  "bf16" rounds confidences to bf16 as the reference's bf16 arithmetic does (F5)
+  noise_source   object supplying sampling noise (tests inject recorded noise; default: device RNG)
+"""
+from __future__ import annotations
+
+import copy
+import warnings
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from transformers import __version__ as _tf_version
+from transformers.generation.configuration_utils import GenerationConfig
+from transformers.utils import ModelOutput, logging
+
+from . import _lib
+
+logger = logging.get_logger(__name__)
+
+_FIELDS = dict(temperature=0.0, top_p=None, top_k=None, max_length=20, max_new_tokens=None, eps=1e-3, steps=512,
+               alg="origin", alg_temp=None, num_return_sequences=1, return_dict_in_generate=False, output_history=False,
+               mask_token_id=None, pad_token_id=None, bos_token_id=None, eos_token_id=None,
+               block_length=None, round_conf_to=None)
+_TOKEN_FIELDS = ("bos_token_id", "eos_token_id", "pad_token_id", "mask_token_id")
+
+
+@dataclass
+class DLMModelOutput(ModelOutput):
+    sequences: torch.LongTensor = None
+    history: Optional[Tuple[torch.FloatTensor]] = None
+
+
+class DLMGenerationConfig(GenerationConfig):
+    """Attribute bag with the reference's fields/defaults (generation_utils.py:109-159); validate() is a no-op there."""
+
+    def __init__(self, **kwargs):
+        for name, default in _FIELDS.items():
+            setattr(self, name, kwargs.pop(name, default))
+        self.generation_kwargs = kwargs.pop("generation_kwargs", {})
+        self._from_model_config = kwargs.pop("_from_model_config", False)
+        self._commit_hash = kwargs.pop("_commit_hash", None)
+        self.transformers_version = kwargs.pop("transformers_version", _tf_version)
+        if not self._from_model_config:
+            for key, value in kwargs.items():
+                setattr(self, key, value)
+
+    def validate(self, *args, **kwargs):
+        return None
+
+    def update(self, **kwargs):
+        """Overlays known attributes, returns the kwargs that were not consumed."""
+        unused = {}
+        for key, value in kwargs.items():
+            if hasattr(self, key):
+                setattr(self, key, value)
+            else:
+                unused[key] = value
+        return unused
+
+    @classmethod
+    def from_model_config(cls, model_config):
+        picked = {k: getattr(model_config, k) for k in _TOKEN_FIELDS if getattr(model_config, k, None) is not None}
+        return cls(_from_model_config=True, **picked)
+
+
+# ---------------------------------------------------------------------------------- noise
+class DeviceNoise:
+    """Default sampling noise.  Token noise (temperature > 0) is generated inside the lm-head
+    kernel from a counter hash keyed by this seed; selection / origin noise comes from torch's
+    device generator.  ``torch.manual_seed`` therefore makes a run reproducible."""
+
+    def __init__(self, device):
+        self.device = device
+        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+
+    def token_noise(self, step, cap_rows, V, picked=None):
+        return None
+
+    def step_seed(self, step):
+        return (self.seed + 0x9E3779B97F4A7C15 * (step + 1)) & 0xFFFFFFFFFFFFFFFF
+
+    def select_noise(self, step, B, L):
+        return torch.empty(B, L, device=self.device, dtype=torch.float32).exponential_(1)
+
+    def origin_uniform(self, step, cap_rows):
+        return torch.rand(cap_rows, device=self.device, dtype=torch.float32)
+
+
+def fp32_schedule(steps_per_block: int, eps: float):
+    """(1 - s/t) per step in fp32, with the reference's tensor arithmetic (generation_utils.py:450,463-464,509)."""
+    ts = torch.linspace(1, eps, steps_per_block + 1)
+    return [float(1 - ts[j + 1] / ts[j]) for j in range(steps_per_block)]
+
+
+def plan_windows(prompt_len: int, gen_len: int, steps: int, block_length):
+    """-> (n_blocks, block_len, steps_per_block); reference mode is one block spanning the row."""
+    if block_length is None or block_length == gen_len:
+        return 1, gen_len, steps
+    if block_length <= 0 or gen_len % block_length:
+        raise ValueError(f"block_length={block_length} must divide max_new_tokens={gen_len}")
+    n_blocks = gen_len // block_length
+    if steps % n_blocks:
+        raise ValueError(f"steps={steps} must be a multiple of the number of blocks ({n_blocks})")
+    return n_blocks, block_length, steps // n_blocks
+
+
+class DLMGenerationMixin:
+    @staticmethod
+    def _expand_inputs_for_generation(expand_size=1, input_ids=None, attention_mask=None):
+        if expand_size == 1:
+            return input_ids, attention_mask
+        if input_ids is not None:
+            input_ids = input_ids.repeat_interleave(expand_size, dim=0)
+        if attention_mask is not None:
+            attention_mask = attention_mask.repeat_interleave(expand_size, dim=0)
+        return input_ids, attention_mask
+
+    def _prepare_generation_config(self, generation_config, **kwargs):
+        from_model = generation_config is None
+        if from_model:
+            generation_config = DLMGenerationConfig.from_model_config(self.config)
+        generation_config = copy.deepcopy(generation_config)
+        generation_config.update(**kwargs)
+        for name in _FIELDS:                         # configs built by other code may lack the added fields
+            if not hasattr(generation_config, name):
+                setattr(generation_config, name, _FIELDS[name])
+        if not from_model:
+            for name in _TOKEN_FIELDS:
+                if getattr(generation_config, name, None) is None:
+                    setattr(generation_config, name, getattr(self.generation_config, name, None))
+        if generation_config.mask_token_id is None:
+            generation_config.mask_token_id = getattr(self.config, "mask_token_id", None)
+        return generation_config
+
+    def _prepare_generated_length(self, generation_config, has_default_max_length, input_ids_length):
+        if generation_config.max_new_tokens is not None:
+            if not has_default_max_length and generation_config.max_length is not None:
+                logger.warning(
+                    f"Both `max_new_tokens` (={generation_config.max_new_tokens}) and `max_length`(="
+                    f"{generation_config.max_length}) seem to have been set. `max_new_tokens` will take precedence.")
+            generation_config.max_length = generation_config.max_new_tokens + input_ids_length
+        elif has_default_max_length and generation_config.max_length == _FIELDS["max_length"]:
+            generation_config.max_length = generation_config.max_length + input_ids_length
+            cap = getattr(self.config, "max_position_embeddings", None)
+            if cap is not None:
+                generation_config.max_length = min(generation_config.max_length, cap)
+        return generation_config
+
+    def _validate_generated_length(self, generation_config, input_ids_length, has_default_max_length):
+        if has_default_max_length and generation_config.max_new_tokens is None and generation_config.max_length == 20:
+            warnings.warn(
+                f"Using the model-agnostic default `max_length` (={generation_config.max_length}) to control the "
+                "generation length. We recommend setting `max_new_tokens` to control the maximum length of the generation.",
+                UserWarning)
+        if input_ids_length >= generation_config.max_length:
+            raise ValueError(
+                f"Input length of input_ids is {input_ids_length}, but `max_length` is set to"
+                f" {generation_config.max_length}. This can lead to unexpected behavior. You should consider"
+                " increasing `max_length` or, better yet, setting `max_new_tokens`.")
+
+    @torch.no_grad()
+    def diffusion_generate(self, inputs: Optional[torch.Tensor] = None,
+                           generation_config: Optional[DLMGenerationConfig] = None, **kwargs):
+        tokens_hook = kwargs.pop("generation_tokens_hook_func", None)
+        logits_hook = kwargs.pop("generation_logits_hook_func", None)
+        attention_mask = kwargs.pop("attention_mask", None)
+        noise_source = kwargs.pop("noise_source", None)
+        had_max_length_kwarg = kwargs.get("max_length") is not None
+        generation_config = self._prepare_generation_config(generation_config, **kwargs)
+
+        assert inputs is not None
+        input_ids = inputs
+        P = input_ids.shape[-1]
+        has_default_max_length = (not had_max_length_kwarg) and generation_config.max_length is not None
+        generation_config = self._prepare_generated_length(generation_config, has_default_max_length, P)
+        self._validate_generated_length(generation_config, P, has_default_max_length)
+
+        if self.device.type != input_ids.device.type:
+            warnings.warn(
+                "You are calling .generate() with the `input_ids` being on a device type different than your model's"
+                f" device. `input_ids` is on {input_ids.device.type}, whereas the model is on {self.device.type}.",
+                UserWarning)
+        self._prompt_has_pad = None
+        if generation_config.pad_token_id is not None and attention_mask is None:
+            # the reference's one pre-loop host sync (generation_utils.py:386-395); the mask-in-prompt probe rides on it
+            probe = torch.stack([(input_ids == generation_config.pad_token_id).any(),
+                                 (input_ids == generation_config.mask_token_id).any()]).tolist()
+            if probe[0]:
+                warnings.warn(
+                    "Padding was detected but no attention mask is passed here. For correct generation results, please "
+                    "set `attention_mask` when batch-padding inputs.", UserWarning)
+            self._prompt_has_mask = bool(probe[1])
+        else:
+            self._prompt_has_mask = bool((input_ids == generation_config.mask_token_id).any().item())
+
+        input_ids, attention_mask = self._expand_inputs_for_generation(
+            generation_config.num_return_sequences, input_ids, attention_mask)
+        return self._sample(input_ids, attention_mask, generation_config, tokens_hook, logits_hook, noise_source)
+
+    # ------------------------------------------------------------------------------ the denoise loop
+    def _sample(self, input_ids, attention_mask, generation_config, tokens_hook, logits_hook, noise_source=None):
+        """Device-resident restatement of the reference loop (generation_utils.py:412-552).
+        ``attention_mask`` is accepted and has no effect, as in the reference."""
+        gc = generation_config
+        alg, alg_temp, temperature = gc.alg, gc.alg_temp, float(gc.temperature or 0.0)
+        if alg not in ("origin", "maskgit_plus", "topk_margin", "entropy"):
+            raise RuntimeError(f"Unknown alg: {alg}")
+        eng = self.hip_engine()
+        eng.set_mask_id(gc.mask_token_id)
+        want_history = bool(gc.return_dict_in_generate and gc.output_history)
+        histories = [] if want_history else None
+
+        P = input_ids.shape[1]
+        x = F.pad(input_ids, (0, gc.max_length - P), value=gc.mask_token_id).to(torch.int64).contiguous()
+        B, L = x.shape
+        G = L - P
+        n_blocks, bl, steps_b = plan_windows(P, G, gc.steps, gc.block_length)
+        ratios = fp32_schedule(steps_b, gc.eps)
+        noise = noise_source if noise_source is not None else DeviceNoise(x.device)
+        round_conf = gc.round_conf_to in ("bf16", torch.bfloat16, "bfloat16")
+        top_p = gc.top_p if (gc.top_p is not None and gc.top_p < 1) else None
+        top_k = gc.top_k
+        materialise_all = logits_hook is not None or tokens_hook is not None
+        fused = not materialise_all and top_p is None and top_k is None
+        alg_id = _lib.ALG_IDS.get(alg, 0)
+        a_temp = float(alg_temp) if alg_temp else 0.0
+
+        if tokens_hook is not None:
+            x = tokens_hook(None, x, None)
+        for i in range(gc.steps):
+            blk, j = divmod(i, steps_b)
+            if n_blocks == 1:
+                # reference mode: every masked position of the row is a candidate (prompt included if it holds masks)
+                lo, hi = (0 if self._prompt_has_mask or tokens_hook is not None else P), L
+            else:
+                lo, hi = P + blk * bl, P + (blk + 1) * bl
+            cap = B * (hi - lo)
+            last = j == steps_b - 1
+
+            hn = eng.forward_hidden(x)
+            eng.build_candidates(x, lo, hi)
+            u = picked = None
+            if alg == "origin":
+                p_transfer = 1.0 if last else ratios[j]
+                u = noise.origin_uniform(i, cap)
+                picked = u < p_transfer
+            tok_noise = noise.token_noise(i, cap, eng.V, picked) if temperature > 0 else None
+            seed = noise.step_seed(i) if (temperature > 0 and tok_noise is None) else 0
+            logits = None
+            if fused:
+                eng.lmhead_confidence(cap, alg_id, temperature, tok_noise, seed, round_conf)
+            elif not materialise_all:
+                rows = eng.candidate_logits(cap)
+                eng.confidence_from_logits(rows, alg_id, temperature, top_p, top_k, tok_noise, seed, round_conf)
+            else:
+                full = eng.logits(x)                                          # [B, L, V]
+                logits = torch.cat([full[:, :1], full[:, :-1]], dim=1)        # logits[p] predicts token p
+                if logits_hook is not None:
+                    logits = logits_hook(i, x, logits)
+                rows = logits.reshape(B * L, -1).index_select(0, eng.dst_pos[:cap].long())
+                if rows.dtype not in (torch.bfloat16, torch.float32):
+                    rows = rows.float()
+                eng.confidence_from_logits(rows.contiguous(), alg_id, temperature, top_p, top_k, tok_noise, seed, round_conf)
+
+            if alg == "origin":
+                eng.origin_transfer(x, cap, u, p_transfer)
+            else:
+                sel_noise = noise.select_noise(i, B, L) if a_temp > 0 else None
+                eng.select_unmask(x, lo, hi, ratios[j], last, a_temp, sel_noise)
+
+            if tokens_hook is not None:
+                x = tokens_hook(i, x, logits)
+            if histories is not None:
+                histories.append(x.clone())
+
+        if gc.return_dict_in_generate:
+            return DLMModelOutput(sequences=x, history=histories)
+        return x

@@ -1,0 +1,129 @@
+/* coda_hip.h - C ABI of libcoda_hip.so: hand-written CDNA4 (gfx950, MI355X) kernels for the
+ * masked-diffusion denoising sampler of CoDA (CoDALanguageModel.diffusion_generate).
+ *
+ * The reference is 100 % Python/PyTorch and has no FFI for this path; every
+ * entry point below replaces a sequence of PyTorch ops of the reference, cited as file:line
+ * relative to the reference checkout.  Conventions:
+ *   - plain pointers to DEVICE memory, sizes and a hipStream_t passed as void*; no torch types;
+ *   - every call only enqueues work on `stream` and returns (no sync, no allocation);
+ *   - return value: 0 = ok, <0 = error (CODA_ERR_*); nothing is launched on error;
+ *   - bf16 tensors are raw uint16 storage, row-major, leading dimensions in ELEMENTS;
+ *   - no ownership transfer: all buffers (including workspaces) belong to the caller.
+ */
+#ifndef CODA_HIP_H
+#define CODA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CODA_ABI_VERSION 1
+
+#define CODA_OK 0
+#define CODA_ERR_SHAPE (-1)  /* unsupported / inconsistent dimensions */
+#define CODA_ERR_ALIGN (-2)  /* pointer or leading dimension not aligned as required */
+#define CODA_ERR_LAUNCH (-3) /* HIP launch failure */
+#define CODA_ERR_ARG (-4)    /* null pointer / bad enum */
+
+/* epilogues of coda_gemm_bf16 */
+#define CODA_EPI_PLAIN 0    /* C = bf16(X W^T) */
+#define CODA_EPI_RESIDUAL 1 /* C = bf16(bf16(X W^T) + R)                    modeling_coda.py:247,253 */
+#define CODA_EPI_SWIGLU 2   /* C = bf16(bf16(silu(gate)) * up), W = gate|up interleaved per 16 rows; :59 */
+#define CODA_EPI_F32 3      /* C = fp32(X W^T) */
+
+/* confidence algorithms (generation_utils.py:485-506) */
+#define CODA_ALG_MASKGIT_PLUS 0
+#define CODA_ALG_TOPK_MARGIN 1
+#define CODA_ALG_ENTROPY 2
+
+int coda_version(void);
+
+/* Last HIP error string seen by the library on this thread (for diagnostics). */
+const char* coda_last_error(void);
+
+/* embed_tokens lookup.  Replaces modeling_coda.py:318.
+ * ids int64 [T]; table bf16 [V,H]; out bf16 [T,H].  H % 8 == 0.  ids outside [0,V) -> CODA_ERR not
+ * detectable on device: rows are clamped to [0,V-1]. */
+int coda_embed_gather(const long long* ids, const void* table, void* out, int T, int V, int H, void* stream);
+
+/* CoDARMSNorm.  Replaces modeling_coda.py:36-41 (fp32 x*rsqrt(mean(x^2)+eps) -> bf16 -> * weight).
+ * x, out bf16 [T,H] (ld in elements), weight bf16 [H].  H % 8 == 0. */
+int coda_rmsnorm(const void* x, long long ldx, const void* weight, void* out, long long ldo, int T, int H, float eps,
+                 void* stream);
+
+/* Linear layers.  Replaces nn.Linear at modeling_coda.py:58-60,123-125,155,411 and the ops fused
+ * behind them (see CODA_EPI_*).  X bf16 [M,K] (optionally row-gathered: row i is X[x_rows[i]]),
+ * W bf16 [N,K] (nn.Linear layout), C [M,N] (SWIGLU: [M,N/2]).  K % 64 == 0, N % 4 == 0. */
+int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, const void* W, long long ldw, void* C,
+                   long long ldc, const void* R, long long ldr, int M, int N, int K, int epilogue, void* stream);
+
+/* q_norm / k_norm + rotary embedding, in place on the fused QKV activation.
+ * Replaces modeling_coda.py:128-148 and modeling_utils.py:70-101.
+ * qkv bf16 [T, (n_q + 2 n_kv) * 128]: q heads, then k heads, then v heads (v untouched).
+ * cos/sin bf16 [L,128] (already cast to bf16 as the reference does, modeling_coda.py:197);
+ * position of token t is t % L.  head_dim must be 128. */
+int coda_qknorm_rope(void* qkv, long long ld, const void* q_weight, const void* k_weight, const void* cos,
+                     const void* sin, int T, int L, int n_q, int n_kv, float eps, void* stream);
+
+/* Non-causal, mask-free GQA flash attention.  Replaces attention.py:12-90 (repeat_kv + SDPA with
+ * is_causal=False and no mask).  Reads q/k/v from the fused QKV activation
+ * (layout as above), writes out bf16 [T, n_q*128] (token-major, heads concatenated: what o_proj
+ * consumes, modeling_coda.py:153-154).  T = B*L, head_dim 128, n_q % n_kv == 0. */
+int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void* out, long long ld_out, int B, int L, int n_q,
+                              int n_kv, float scale, void* stream);
+
+/* Candidate list for one denoise step.  Replaces `mask_index = x == mask_token_id`,
+ * the shift `cat(logits[:, :1], logits[:, :-1])` and the boolean gather `logits[mask_index]`
+ * (generation_utils.py:455-462) without touching logits: for every masked position p of row b
+ * inside [win_lo, win_hi), in row-major order, emits src_row = b*L + max(p-1,0) (the hidden row
+ * whose lm-head output predicts p) and dst = b*L + p.  count[0] receives the number of
+ * candidates.  src_rows/dst_pos must hold B*(win_hi-win_lo) ints. */
+int coda_build_candidates(const long long* x, int B, int L, int win_lo, int win_hi, long long mask_id, int* src_rows,
+                          int* dst_pos, int* count, void* stream);
+
+/* Fused lm-head + online softmax + confidence.  Replaces modeling_coda.py:411 (lm_head) and
+ * generation_utils.py:61-100 (sample_tokens) for top_p = top_k = None; never materialises logits.
+ * hidden bf16 [*, H] final-normed hidden states; src_rows/count from coda_build_candidates;
+ * W bf16 [V,H].  For candidate i: logits = bf16(hidden[src_rows[i]] W^T) (/temperature if > 0),
+ * x0 = argmax (first index) or, if temperature > 0, argmax(logit - log(noise)) with
+ * noise fp32 [max_rows, V] ~ Exp(1) (the exponential race of Categorical.sample());
+ * noise == NULL with temperature > 0: Exp(1) variates come from an in-kernel counter hash of
+ * (seed, dst_pos[i], vocab index) - see coda_amd/rng.py for the host restatement;
+ * confidence per `alg`.  Outputs are written at conf[dst_pos[i]], x0[dst_pos[i]].
+ * workspace: coda_lmhead_workspace_bytes(max_rows, V) bytes.  max_rows bounds the grid; rows
+ * beyond count[0] do no work.  H % 64 == 0, V % 4 == 0. */
+long long coda_lmhead_workspace_bytes(int max_rows, int V);
+int coda_lmhead_confidence(const void* hidden, long long ld_hidden, const int* src_rows, const int* dst_pos,
+                           const int* count, int max_rows, const void* W, long long ldw, int V, int H, int alg,
+                           float temperature, const float* noise, unsigned long long seed, int round_conf_bf16,
+                           float* conf, long long* x0, void* workspace, void* stream);
+
+/* Unfused confidence from materialised logits (hooks, top-p, top-k).  Replaces
+ * generation_utils.py:39-100.  logits bf16 or fp32 [N,V] (is_bf16), one row per candidate i < count[0]
+ * (count may be NULL: all N rows).  top_p <= 0 or >= 1 disables top-p; top_k <= 0 disables top-k.
+ * Outputs at conf[dst_pos[i]], x0[dst_pos[i]] (dst_pos NULL: at i). */
+int coda_confidence_from_logits(const void* logits, long long ld, int is_bf16, int N, int V, const int* count,
+                                const int* dst_pos, int alg, float temperature, float top_p, int top_k,
+                                const float* noise, unsigned long long seed, int round_conf_bf16, float* conf,
+                                long long* x0, void* stream);
+
+/* Schedule + selection + scatter.  Replaces generation_utils.py:507-538.
+ * k = trunc((count/B) * ratio) in fp32 (ratio = 1 - s/t computed by the host exactly as the
+ * reference does; take_all != 0 on the last step of a schedule: k = trunc(count/B)).
+ * Per row b, among masked positions in [win_lo, win_hi): alg_temp == 0 -> the k largest conf
+ * (ties: lowest index); alg_temp > 0 -> the k largest softmax(conf/alg_temp)/noise with
+ * noise fp32 [B,L] ~ Exp(1) (== torch.multinomial without replacement).  Writes x[b,p] = x0[b,p]
+ * in place for the selected p.  k_out (nullable) receives k. */
+int coda_select_unmask(long long* x, const float* conf, const long long* x0, const int* count, int B, int L,
+                       int win_lo, int win_hi, long long mask_id, float ratio, int take_all, float alg_temp,
+                       const float* noise, int* k_out, void* stream);
+
+/* `origin` algorithm transfer (generation_utils.py:466-483): every candidate i < count[0] with
+ * u[i] < p_transfer takes x[dst_pos[i]] = x0[dst_pos[i]].  u fp32 [count] uniform(0,1). */
+int coda_origin_transfer(long long* x, const long long* x0, const int* dst_pos, const int* count, int max_rows,
+                         const float* u, float p_transfer, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CODA_HIP_H */

@@ -275,7 +275,8 @@ class SamplerTrace:
 
 def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.Tensor,
                 args: SamplerArgs, noise=None, tokens_hook=None, logits_hook=None,
-                trace: bool = False, force_states: Optional[List[torch.Tensor]] = None) -> SamplerTrace:
+                trace: bool = False, force_states: Optional[List[torch.Tensor]] = None,
+                max_steps: Optional[int] = None) -> SamplerTrace:
     """``logits_fn(x) -> [B, L, V]`` unshifted logits.  ``force_states[i]`` (optional) replaces
     ``x`` at the start of step i (teacher forcing, used by per-step parity checks)."""
     noise = noise or TorchNoise()
@@ -297,6 +298,8 @@ def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: to
     if tokens_hook is not None:
         x = tokens_hook(None, x, None)
     for i in range(args.steps):
+        if max_steps is not None and i >= max_steps:      # bounded sample of the loop (bench.py cpu_baseline)
+            break
         if force_states is not None:
             x = force_states[i].clone()
         blk, j = divmod(i, steps_b)
@@ -357,14 +360,15 @@ def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: to
 def diffusion_generate(sd, dims: Dims, input_ids: torch.Tensor, *, max_new_tokens: int, steps: int,
                        alg: str = "origin", alg_temp=None, temperature: float = 0.0, top_p=None, top_k=None,
                        eps: float = 1e-3, block_length=None, noise=None, trace: bool = False,
-                       tokens_hook=None, logits_hook=None, force_states=None) -> SamplerTrace:
+                       tokens_hook=None, logits_hook=None, force_states=None, max_steps=None) -> SamplerTrace:
     """Oracle twin of ``model.diffusion_generate`` for equal-length prompts."""
     args = SamplerArgs(max_length=input_ids.shape[1] + max_new_tokens, steps=steps, mask_id=dims.mask_id, eps=eps,
                        alg=alg, alg_temp=alg_temp, temperature=temperature, top_p=top_p, top_k=top_k,
                        block_length=block_length, output_history=True)
     with torch.no_grad():
         return sample_loop(lambda x: forward_logits(sd, dims, x), input_ids, args, noise=noise,
-                           tokens_hook=tokens_hook, logits_hook=logits_hook, trace=trace, force_states=force_states)
+                           tokens_hook=tokens_hook, logits_hook=logits_hook, trace=trace, force_states=force_states,
+                           max_steps=max_steps)
 
 
 # --------------------------------------------------------------------------- online forms (SURVEY A.4)

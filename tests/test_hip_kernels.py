@@ -1,0 +1,421 @@
+"""Per-kernel parity of the HIP path (through the C ABI) against the CPU oracle / plain torch fp32.
+
+Integer-valued operands make the GEMM-shaped checks BIT-EXACT (every product and partial sum is
+exactly representable), so a wrong MFMA lane map, swizzle or epilogue index cannot hide behind a
+tolerance; random-normal operands then check the numerics at realistic scale."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from coda_amd import _lib  # noqa: E402
+from oracle import ref_cpu  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def gemm(X, W, epi, R=None, rows=None, M=None, out_cols=None):
+    M = X.shape[0] if M is None else M
+    N, K = W.shape
+    cols = out_cols or (N // 2 if epi == _lib.EPI_SWIGLU else N)
+    C = torch.full((M, cols), float("nan"), device=DEV, dtype=torch.float32 if epi == _lib.EPI_F32 else BF)
+    _lib.call("coda_gemm_bf16", _p(X), X.stride(0), _p(rows), _p(W), W.stride(0), _p(C), C.stride(0), _p(R),
+              0 if R is None else R.stride(0), M, N, K, epi, _s())
+    torch.cuda.synchronize()
+    return C
+
+
+def int_mat(shape, lo, hi, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi + 1, shape, generator=g).to(BF)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (200, 132, 192), (1, 4, 64), (300, 1024, 256)])
+def test_gemm_exact_integer(M, N, K):
+    X, W = int_mat((M, K), -3, 3, 1), int_mat((N, K), -2, 2, 2)       # asymmetric operands
+    ref = X.float() @ W.float().t()
+    out = gemm(X.to(DEV), W.to(DEV), _lib.EPI_F32).cpu()
+    assert torch.equal(out, ref)
+    out = gemm(X.to(DEV), W.to(DEV), _lib.EPI_PLAIN).cpu()
+    assert torch.equal(out, ref.to(BF))
+
+
+def test_gemm_identity_asymmetric():
+    K = 128
+    X = torch.eye(K).to(BF)
+    W = (torch.arange(K * K).reshape(K, K) % 17 - 8).to(BF)             # W[n][k] asymmetric
+    out = gemm(X.to(DEV), W.to(DEV), _lib.EPI_F32).cpu()
+    assert torch.equal(out, W.float().t())
+
+
+def test_gemm_residual_and_gather():
+    M, N, K = 260, 256, 128
+    X, W = int_mat((M, K), -3, 3, 3), int_mat((N, K), -2, 2, 4)
+    R = int_mat((M, N), -50, 50, 5)
+    ref = ((X.float() @ W.float().t()).to(BF).float() + R.float()).to(BF)
+    out = gemm(X.to(DEV), W.to(DEV), _lib.EPI_RESIDUAL, R=R.to(DEV)).cpu()
+    assert torch.equal(out, ref)
+    # in place (C aliases R), as the decoder uses it
+    Rd = R.to(DEV).clone()
+    _lib.call("coda_gemm_bf16", _p(X.to(DEV)), K, None, _p(W.to(DEV)), K, _p(Rd), N, _p(Rd), N, M, N, K, _lib.EPI_RESIDUAL, _s())
+    torch.cuda.synchronize()
+    assert torch.equal(Rd.cpu(), ref)
+    # row gather
+    g = torch.Generator().manual_seed(6)
+    rows = torch.randint(0, M, (77,), generator=g).to(torch.int32)
+    out = gemm(X.to(DEV), W.to(DEV), _lib.EPI_F32, rows=rows.to(DEV), M=77).cpu()
+    assert torch.equal(out, X.float()[rows.long()] @ W.float().t())
+
+
+def test_gemm_swiglu():
+    from coda_amd.engine import interleave_gate_up
+    M, I, K = 130, 192, 128
+    g = torch.Generator().manual_seed(7)
+    X = (torch.randn(M, K, generator=g)).to(BF)
+    Wg, Wu = (torch.randn(I, K, generator=g) * 0.1).to(BF), (torch.randn(I, K, generator=g) * 0.1).to(BF)
+    gate = (X.float() @ Wg.float().t()).to(BF)
+    up = (X.float() @ Wu.float().t()).to(BF)
+    ref = torch.nn.functional.silu(gate) * up
+    out = gemm(X.to(DEV), interleave_gate_up(Wg, Wu).to(DEV), _lib.EPI_SWIGLU).cpu()
+    # same rounding points as the reference op sequence; accumulation order may move a value by one bf16 ulp
+    err = (out.float() - ref.float()).abs()
+    assert (err <= 2.0 ** -7 * ref.float().abs() + 1e-3).all()
+    assert (out == ref).float().mean() > 0.98
+
+
+def test_gemm_random_tolerance():
+    M, N, K = 512, 768, 2048
+    g = torch.Generator().manual_seed(8)
+    X, W = torch.randn(M, K, generator=g).to(BF), (torch.randn(N, K, generator=g) * 0.02).to(BF)
+    ref = X.float() @ W.float().t()
+    out = gemm(X.to(DEV), W.to(DEV), _lib.EPI_F32).cpu()
+    assert (out - ref).abs().max() < 2e-4 * math.sqrt(K)
+
+
+def test_gemm_rejects_bad_shapes():
+    X = torch.zeros(4, 60, device=DEV, dtype=BF)
+    W = torch.zeros(8, 60, device=DEV, dtype=BF)
+    C = torch.zeros(4, 8, device=DEV, dtype=BF)
+    rc = _lib.load().coda_gemm_bf16(_p(X), 60, None, _p(W), 60, _p(C), 8, None, 0, 4, 8, 60, 0, _s())
+    assert rc == -1
+
+
+def test_embed_and_rmsnorm():
+    g = torch.Generator().manual_seed(9)
+    V, H, T = 300, 256, 37
+    table = torch.randn(V, H, generator=g).to(BF)
+    ids = torch.randint(0, V, (T,), generator=g)
+    out = torch.empty(T, H, device=DEV, dtype=BF)
+    _lib.call("coda_embed_gather", _p(ids.to(DEV)), _p(table.to(DEV)), _p(out), T, V, H, _s())
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), table[ids])
+    for H in (256, 2048, 4608):
+        x = (torch.randn(T, H, generator=g) * 3).to(BF)
+        w = (1 + 0.1 * torch.randn(H, generator=g)).to(BF)
+        y = torch.empty(T, H, device=DEV, dtype=BF)
+        _lib.call("coda_rmsnorm", _p(x.to(DEV)), H, _p(w.to(DEV)), _p(y), H, T, H, 1e-6, _s())
+        torch.cuda.synchronize()
+        ref = ref_cpu._rms(x, w, 1e-6)
+        same = (y.cpu() == ref).float().mean().item()
+        assert same > 0.995, same                                   # summation order may flip a rare rounding
+        assert (y.cpu().float() - ref.float()).abs().max() <= 2.0 ** -6 * ref.float().abs().max()
+
+
+def test_qknorm_rope():
+    g = torch.Generator().manual_seed(10)
+    B, L, n_q, n_kv, d = 2, 50, 4, 2, 128
+    T = B * L
+    qkv = torch.randn(T, (n_q + 2 * n_kv) * d, generator=g).to(BF)
+    qw, kw = (1 + 0.1 * torch.randn(d, generator=g)).to(BF), (1 + 0.1 * torch.randn(d, generator=g)).to(BF)
+    cos, sin = ref_cpu.rope_tables(L, d, 1000000, BF)
+    dq = qkv.to(DEV).clone()
+    _lib.call("coda_qknorm_rope", _p(dq), dq.stride(0), _p(qw.to(DEV)), _p(kw.to(DEV)), _p(cos.to(DEV)), _p(sin.to(DEV)),
+              T, L, n_q, n_kv, 1e-6, _s())
+    torch.cuda.synchronize()
+    q = ref_cpu._rms(qkv[:, : n_q * d].view(B, L, n_q, d), qw, 1e-6).transpose(1, 2)
+    k = ref_cpu._rms(qkv[:, n_q * d:(n_q + n_kv) * d].view(B, L, n_kv, d), kw, 1e-6).transpose(1, 2)
+    q = q * cos[None, None] + ref_cpu._rot_half(q) * sin[None, None]
+    k = k * cos[None, None] + ref_cpu._rot_half(k) * sin[None, None]
+    ref = qkv.clone()
+    ref[:, : n_q * d] = q.transpose(1, 2).reshape(T, n_q * d)
+    ref[:, n_q * d:(n_q + n_kv) * d] = k.transpose(1, 2).reshape(T, n_kv * d)
+    out = dq.cpu()
+    assert torch.equal(out[:, (n_q + n_kv) * d:], qkv[:, (n_q + n_kv) * d:])      # V untouched
+    assert (out == ref).float().mean() > 0.995
+    assert (out.float() - ref.float()).abs().max() < 0.05
+
+
+@pytest.mark.parametrize("B,L,n_q,n_kv", [(1, 64, 2, 1), (2, 100, 4, 2), (1, 384, 16, 8), (1, 517, 2, 2)])
+def test_flash_attention(B, L, n_q, n_kv):
+    g = torch.Generator().manual_seed(11)
+    d, T = 128, B * L
+    qkv = torch.randn(T, (n_q + 2 * n_kv) * d, generator=g).to(BF)
+    # spike one key against one query so the running max jumps late (online-softmax rescale path)
+    qkv[L - 3, :d] *= 6
+    qkv[L - 3, n_q * d: n_q * d + d] = qkv[L - 3, :d]
+    out = torch.full((T, n_q * d), float("nan"), device=DEV, dtype=BF)
+    _lib.call("coda_flash_attn_noncausal", _p(qkv.to(DEV)), qkv.stride(0), _p(out), n_q * d, B, L, n_q, n_kv,
+              1.0 / math.sqrt(d), _s())
+    torch.cuda.synchronize()
+    q = qkv[:, : n_q * d].view(B, L, n_q, d).transpose(1, 2).float()
+    k = qkv[:, n_q * d:(n_q + n_kv) * d].view(B, L, n_kv, d).transpose(1, 2).float().repeat_interleave(n_q // n_kv, 1)
+    v = qkv[:, (n_q + n_kv) * d:].view(B, L, n_kv, d).transpose(1, 2).float().repeat_interleave(n_q // n_kv, 1)
+    ref = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), -1) @ v
+    ref = ref.transpose(1, 2).reshape(T, n_q * d)
+    err = (out.cpu().float() - ref).abs().max().item()
+    assert err < 2e-2, err
+
+
+def test_flash_attention_exact_uniform():
+    """All-equal scores: softmax is uniform, so O = mean(V); with integer V this checks the V transposed-read
+    mapping and the P/V k-order pairing without tolerance slack."""
+    B, L, n_q, n_kv, d = 1, 128, 2, 1, 128
+    T = B * L
+    qkv = torch.zeros(T, (n_q + 2 * n_kv) * d)
+    g = torch.Generator().manual_seed(12)
+    V = torch.randint(-4, 5, (T, d), generator=g).float()
+    qkv[:, (n_q + n_kv) * d:] = V
+    out = torch.empty(T, n_q * d, device=DEV, dtype=BF)
+    _lib.call("coda_flash_attn_noncausal", _p(qkv.to(BF).to(DEV)), qkv.stride(0), _p(out), n_q * d, B, L, n_q, n_kv, 0.1, _s())
+    torch.cuda.synchronize()
+    ref = V.mean(0, keepdim=True).expand(T, d)
+    assert (out.cpu().float()[:, :d] - ref).abs().max() < 2e-2
+    # one-hot attention: query i matches key perm[i] only -> O[i] = V[perm[i]] exactly
+    perm = torch.randperm(L, generator=g)
+    code = torch.zeros(L, d)
+    for i in range(L):
+        for b in range(7):
+            code[i, b] = 1.0 if (i >> b) & 1 else -1.0
+    qkv = torch.zeros(T, (n_q + 2 * n_kv) * d)
+    qkv[:, :d] = code[perm] * 8
+    qkv[:, d:2 * d] = code[perm] * 8
+    qkv[:, n_q * d:(n_q + n_kv) * d] = code * 8
+    qkv[:, (n_q + n_kv) * d:] = V
+    _lib.call("coda_flash_attn_noncausal", _p(qkv.to(BF).to(DEV)), qkv.stride(0), _p(out), n_q * d, B, L, n_q, n_kv, 1.0, _s())
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu().float()[:, :d], V[perm])
+    assert torch.equal(out.cpu().float()[:, d:], V[perm])
+
+
+def _candidates(x, lo, hi, mask_id):
+    B, L = x.shape
+    xd = x.to(DEV)
+    src = torch.zeros(B * (hi - lo), device=DEV, dtype=torch.int32)
+    dst = torch.zeros_like(src)
+    cnt = torch.zeros(1, device=DEV, dtype=torch.int32)
+    _lib.call("coda_build_candidates", _p(xd), B, L, lo, hi, mask_id, _p(src), _p(dst), _p(cnt), _s())
+    torch.cuda.synchronize()
+    return src, dst, cnt
+
+
+def test_build_candidates_order_and_shift():
+    g = torch.Generator().manual_seed(13)
+    B, L, mask_id = 5, 700, 99
+    x = torch.randint(0, 50, (B, L), generator=g)
+    x[torch.rand(B, L, generator=g) < 0.4] = mask_id
+    x[2, 0] = mask_id
+    for lo, hi in ((0, L), (100, 612), (640, 700)):
+        src, dst, cnt = _candidates(x, lo, hi, mask_id)
+        win = torch.zeros_like(x, dtype=torch.bool)
+        win[:, lo:hi] = True
+        pos = ((x == mask_id) & win).nonzero()
+        n = cnt.item()
+        assert n == pos.shape[0]
+        flat = pos[:, 0] * L + pos[:, 1]
+        assert torch.equal(dst[:n].cpu().long(), flat)
+        assert torch.equal(src[:n].cpu().long(), pos[:, 0] * L + (pos[:, 1] - 1).clamp(min=0))
+
+
+@pytest.mark.parametrize("alg_temp", [0.0, 0.3])
+def test_select_unmask_matches_oracle(alg_temp):
+    g = torch.Generator().manual_seed(14)
+    B, L, P, mask_id = 4, 96, 16, 7
+    for trial, (ratio, last) in enumerate(((0.25, False), (0.031, False), (0.5, True), (0.001, False))):
+        x = torch.randint(10, 50, (B, L), generator=g)
+        x[:, P:][torch.rand(B, L - P, generator=g) < 0.6] = mask_id
+        conf = -torch.rand(B, L, generator=g)
+        conf[0, P:P + 8] = -0.5                                             # ties: lowest index must win
+        x0 = torch.randint(100, 200, (B, L), generator=g)
+        noise = torch.empty(B, L).exponential_(1, generator=g)
+        lo, hi = P, L
+        mask_index = x == mask_id
+        n_mask = mask_index.sum() / B
+        k = int(n_mask) if last else int(n_mask * torch.tensor(ratio))
+        expect = x.clone()
+        if k > 0:
+            full = torch.full((B, L), -torch.inf)
+            full[mask_index] = conf[mask_index]
+            key = full if alg_temp == 0 else torch.softmax(full / alg_temp, -1) / noise
+            for b in range(B):
+                nb = int(mask_index[b].sum())
+                order = sorted(range(L), key=lambda p: (-key[b, p].item(), p))[:min(k, nb)]
+                order = [p for p in order if mask_index[b, p]]
+                expect[b, order] = x0[b, order]
+        xd = x.to(DEV)
+        src, dst, cnt = _candidates(x, lo, hi, mask_id)
+        kd = torch.zeros(1, device=DEV, dtype=torch.int32)
+        _lib.call("coda_select_unmask", _p(xd), _p(conf.to(DEV).contiguous()), _p(x0.to(DEV)), _p(cnt), B, L, lo, hi, mask_id,
+                  ratio, int(last), alg_temp, _p(noise.to(DEV)), _p(kd), _s())
+        torch.cuda.synchronize()
+        assert kd.item() == k, (trial, kd.item(), k)
+        assert torch.equal(xd.cpu(), expect), trial
+
+
+def _lmhead(hidden, W, src, dst, cnt, cap, alg, temperature=0.0, noise=None, T_total=None, round_conf=0, seed=0):
+    V, H = W.shape
+    T_total = T_total or hidden.shape[0]
+    conf = torch.full((T_total,), float("nan"), device=DEV)
+    x0 = torch.full((T_total,), -1, device=DEV, dtype=torch.int64)
+    ws = torch.empty(_lib.load().coda_lmhead_workspace_bytes(cap, V), device=DEV, dtype=torch.uint8)
+    _lib.call("coda_lmhead_confidence", _p(hidden), hidden.stride(0), _p(src), _p(dst), _p(cnt), cap, _p(W), W.stride(0), V, H,
+              alg, temperature, _p(noise), seed, round_conf, _p(conf), _p(x0), _p(ws), _s())
+    torch.cuda.synchronize()
+    return conf, x0
+
+
+@pytest.mark.parametrize("V,n_rows", [(1024, 37), (1536 + 4, 300), (5000, 129)])
+def test_lmhead_confidence_exact_logits(V, n_rows):
+    """Integer hidden/weights -> the bf16 logits are exact, so x0 must equal the oracle's argmax (first index on
+    ties) and the fp32 confidences must agree to the 1e-4 bound of SURVEY.md appendix B."""
+    g = torch.Generator().manual_seed(15)
+    H, T = 128, 400
+    hidden = torch.randint(-2, 3, (T, H), generator=g).to(BF)
+    W = torch.randint(-1, 2, (V, H), generator=g).to(BF)
+    logits_all = (hidden.float() @ W.float().t()) * 1.0
+    assert logits_all.abs().max() < 256
+    src = torch.randint(0, T, (n_rows,), generator=g).to(torch.int32)
+    dst = torch.randperm(T, generator=g)[:n_rows].to(torch.int32)
+    cnt = torch.tensor([n_rows], dtype=torch.int32)
+    rows = logits_all[src.long()].to(BF).float() * 0.25            # scale after exact bf16 logits: still exact
+    hid_s = (hidden.float() * 0.25).to(BF)                          # 0.25 scaling is exact in bf16
+    for alg_id, kw in ((0, {}), (1, dict(margin=True)), (2, dict(neg_entropy=True))):
+        c_ref, x_ref = ref_cpu.sample_tokens(rows, 0.0, **kw)
+        conf, x0 = _lmhead(hid_s.to(DEV), W.to(DEV), src.to(DEV), dst.to(DEV), cnt.to(DEV), 512, alg_id, T_total=T)
+        assert torch.equal(x0.cpu()[dst.long()], x_ref)
+        assert (conf.cpu()[dst.long()] - c_ref).abs().max() < 1e-4
+        untouched = torch.ones(T, dtype=torch.bool)
+        untouched[dst.long()] = False
+        assert torch.isnan(conf.cpu()[untouched]).all()
+
+
+def test_lmhead_confidence_sampled_with_injected_noise():
+    g = torch.Generator().manual_seed(16)
+    H, T, V, n_rows = 128, 200, 2048, 70
+    hidden = torch.randint(-2, 3, (T, H), generator=g).to(BF)
+    W = torch.randint(-1, 2, (V, H), generator=g).to(BF)
+    src = torch.arange(n_rows, dtype=torch.int32)
+    dst = torch.arange(n_rows, dtype=torch.int32) + 5
+    cnt = torch.tensor([n_rows], dtype=torch.int32)
+    logits = (hidden.float()[:n_rows] @ W.float().t()).to(BF)
+    q = torch.empty(n_rows, V).exponential_(1, generator=g)
+
+    class N:
+        def token_exp(self, step, probs):
+            return q
+    temp = 0.5
+    c_ref, x_ref = ref_cpu.sample_tokens(logits.float(), temp, noise=N())
+    noise = torch.ones(128, V)
+    noise[:n_rows] = q
+    conf, x0 = _lmhead(hidden.to(DEV), W.to(DEV), src.to(DEV), dst.to(DEV), cnt.to(DEV), 128, 0, temperature=temp,
+                       noise=noise.to(DEV), T_total=T)
+    assert torch.equal(x0.cpu()[dst.long()], x_ref)
+    assert (conf.cpu()[dst.long()] - c_ref).abs().max() < 1e-4
+
+
+def test_lmhead_confidence_full_vocab_random():
+    """Real vocabulary size, random-normal weights: compare against sample_tokens on torch-computed bf16 logits.
+    x0 may differ only where the oracle's top-2 bf16 logits are within one bf16 ulp (declared near-tie band)."""
+    g = torch.Generator().manual_seed(17)
+    H, V, n_rows = 256, 151936, 200
+    hidden = torch.randn(n_rows, H, generator=g).to(BF)
+    W = (torch.randn(V, H, generator=g) * 0.25).to(BF)
+    src = torch.arange(n_rows, dtype=torch.int32)
+    cnt = torch.tensor([n_rows], dtype=torch.int32)
+    logits = (hidden.to(DEV).float() @ W.to(DEV).float().t()).to(BF).float().cpu()
+    for alg_id, kw in ((2, dict(neg_entropy=True)), (1, dict(margin=True)), (0, {})):
+        c_ref, x_ref = ref_cpu.sample_tokens(logits, 0.0, **kw)
+        conf, x0 = _lmhead(hidden.to(DEV), W.to(DEV), src.to(DEV), src.to(DEV), cnt.to(DEV), 256, alg_id, T_total=n_rows)
+        top2 = torch.topk(logits, 2, dim=-1)[0]
+        ulp = 2.0 ** (torch.floor(torch.log2(top2[:, 0].abs())) - 7)
+        near = (top2[:, 0] - top2[:, 1]) <= ulp
+        bad = (x0.cpu() != x_ref) & ~near
+        assert not bad.any(), (alg_id, int(bad.sum()))
+        # confidences are continuous in the logits: a bf16 ulp on a dominant logit moves them by <~ 2^-7 relative
+        assert (conf.cpu() - c_ref).abs().max() < 0.05, alg_id
+        assert (conf.cpu() - c_ref).abs().median() < 2e-3, alg_id
+
+
+def _conf_logits(logits, alg, temperature=0.0, top_p=0.0, top_k=0, noise=None, round_conf=0):
+    N, V = logits.shape
+    conf = torch.full((N,), float("nan"), device=DEV)
+    x0 = torch.full((N,), -1, device=DEV, dtype=torch.int64)
+    ld = logits.to(DEV).contiguous()
+    _lib.call("coda_confidence_from_logits", _p(ld), ld.stride(0), int(ld.dtype == BF), N, V, None, None, alg, temperature,
+              top_p, top_k, _p(None if noise is None else noise.to(DEV)), 0, round_conf, _p(conf), _p(x0), _s())
+    torch.cuda.synchronize()
+    return conf.cpu(), x0.cpu()
+
+
+@pytest.mark.parametrize("V", [1536, 151936])
+def test_confidence_from_logits_all_flavours(V, golden):
+    g = torch.Generator().manual_seed(18)
+    logits = torch.from_numpy(golden["st_logits"]) if V == 1536 else torch.randn(24, V, generator=g) * 4
+    N = logits.shape[0]
+    q = torch.empty(N, V).exponential_(1, generator=g)
+
+    class Nz:
+        def token_exp(self, step, probs):
+            return q
+    cases = [dict(), dict(top_p=0.9), dict(top_k=50), dict(top_p=0.7, top_k=30), dict(top_p=0.95, top_k=5),
+             dict(temperature=0.7, top_p=0.9), dict(temperature=1.3, top_k=20), dict(temperature=0.5)]
+    for kw in cases:
+        for alg_id, okw in ((0, {}), (1, dict(margin=True)), (2, dict(neg_entropy=True))):
+            t = kw.get("temperature", 0.0)
+            c_ref, x_ref = ref_cpu.sample_tokens(logits, t, kw.get("top_p"), kw.get("top_k"), noise=Nz(), **okw)
+            conf, x0 = _conf_logits(logits, alg_id, t, kw.get("top_p", 0.0), kw.get("top_k", 0), q if t > 0 else None)
+            assert torch.equal(x0, x_ref), (kw, alg_id)
+            assert (conf - c_ref).abs().max() < 2e-4, (kw, alg_id, (conf - c_ref).abs().max())
+
+
+def test_confidence_from_logits_bf16_ties():
+    """bf16 logits tie massively; the kept sets of top-p / top-k must follow the documented rule
+    (ties at the top-p boundary enter in index order, ties at the k-th value are all kept)."""
+    g = torch.Generator().manual_seed(19)
+    N, V = 16, 4096
+    logits = (torch.randn(N, V, generator=g) * 2).to(BF)
+    lf = logits.float()
+    for top_p, top_k in ((0.8, 0), (0.0, 40), (0.6, 25)):
+        keep = torch.ones(N, V, dtype=torch.bool)
+        if top_p:
+            p = torch.softmax(lf, -1)
+            order = torch.sort(torch.arange(V)[None].expand(N, V), dim=1)[1]
+            # stable descending sort = ties in index order
+            srt, idx = torch.sort(lf, dim=-1, descending=True, stable=True)
+            ps = p.gather(1, idx)
+            excl = torch.cumsum(ps, -1) - ps
+            kept_sorted = excl <= top_p
+            kept_sorted[:, 0] = True
+            keep = torch.zeros(N, V, dtype=torch.bool).scatter_(1, idx, kept_sorted)
+        if top_k:
+            filt = lf.masked_fill(~keep, torch.finfo(torch.float32).min)
+            kth = torch.topk(filt, top_k)[0][:, -1:]
+            keep = keep & ~(filt < kth)
+        filt = lf.masked_fill(~keep, torch.finfo(torch.float32).min)
+        pr = torch.softmax(filt, -1)
+        ent_ref = (pr * torch.log(pr + 1e-10)).sum(-1)
+        conf, x0 = _conf_logits(logits, 2, 0.0, top_p, top_k)
+        assert torch.equal(x0, lf.argmax(-1))
+        # the cumulative mass is summed in a different order than torch.cumsum: a boundary tie may flip
+        close = (conf - ent_ref).abs() < 2e-4
+        assert close.float().mean() >= 0.8, (top_p, top_k, (conf - ent_ref).abs())

@@ -1,0 +1,170 @@
+"""CPU-side checks: C-ABI library exports, config/generation-config contract, schedules, DP sharding."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "coda_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(coda_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from coda_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _lib.load()
+    names = _declared_symbols()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), n
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == set(names)
+    assert lib.coda_version() == 1
+    assert lib.coda_lmhead_workspace_bytes(1024, 151936) > 0
+
+
+def test_generation_config_fields_and_defaults():
+    from coda_amd import DLMGenerationConfig
+    gc = DLMGenerationConfig()
+    expect = dict(temperature=0.0, top_p=None, top_k=None, max_length=20, max_new_tokens=None, eps=1e-3, steps=512,
+                  alg="origin", alg_temp=None, num_return_sequences=1, return_dict_in_generate=False,
+                  output_history=False, mask_token_id=None, pad_token_id=None, bos_token_id=None, eos_token_id=None)
+    for k, v in expect.items():
+        assert getattr(gc, k) == v, k
+    assert gc.block_length is None
+    left = gc.update(steps=7, alg="entropy", not_a_field=3)
+    assert gc.steps == 7 and gc.alg == "entropy" and left == {"not_a_field": 3}
+    assert gc.validate() is None
+
+
+def test_config_defaults_match_reference_config_json():
+    import json
+    from coda_amd import CoDAConfig
+    c = CoDAConfig()
+    ref = dict(vocab_size=151936, hidden_size=2048, intermediate_size=6144, num_attention_heads=16,
+               num_key_value_heads=8, head_dim=128, num_hidden_layers=28, max_position_embeddings=40960,
+               rms_norm_eps=1e-6, rope_theta=1000000, mask_token_id=151669, pad_token_id=151643, bos_token_id=151643,
+               eos_token_id=151645, attention_kernel="flash_attention", hidden_act="silu", model_type="CoDA")
+    for k, v in ref.items():
+        assert getattr(c, k) == v, k
+    c2 = CoDAConfig.from_dict(json.loads(c.to_json_string()))
+    assert c2.mask_token_id == 151669 and c2.rope_is_plain()
+
+
+def _tiny_model():
+    from coda_amd import CoDAConfig, CoDALanguageModel
+    cfg = CoDAConfig(vocab_size=1024, hidden_size=256, intermediate_size=512, num_attention_heads=2,
+                     num_key_value_heads=1, head_dim=128, num_hidden_layers=2, mask_token_id=1023, pad_token_id=1000,
+                     bos_token_id=1000, eos_token_id=1001)
+    return cfg, CoDALanguageModel(cfg).eval()
+
+
+def test_state_dict_keys_and_untied_lm_head():
+    from oracle import ref_cpu
+    cfg, m = _tiny_model()
+    d = ref_cpu.Dims(vocab=1024, hidden=256, inter=512, heads=2, kv_heads=1, head_dim=128, layers=2, mask_id=1023)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == d.shapes()
+    assert m.lm_head.weight.data_ptr() != m.model.embed_tokens.weight.data_ptr()
+    assert m.mask_token_id == 1023 and m.generation_config.mask_token_id == 1023
+    assert m.get_embeds(torch.tensor([[1, 2]])).shape == (1, 2, 256)
+
+
+def test_auto_model_directory_roundtrip(tmp_path):
+    """HF remote-code directory (config.json auto_map + model_config.py / modeling_coda.py), as callers load it
+    (evaluation/lm_eval/lm_eval/models/diffllm.py:207-215)."""
+    from coda_amd.hf_dir import save_model_dir
+    from transformers import AutoModel, AutoConfig
+    cfg, m = _tiny_model()
+    save_model_dir(m, str(tmp_path))
+    assert {"config.json", "model_config.py", "modeling_coda.py", "model.safetensors"} <= set(os.listdir(tmp_path))
+    c = AutoConfig.from_pretrained(str(tmp_path), trust_remote_code=True)
+    assert type(c).__name__ == "CoDAConfig" and c.mask_token_id == 1023
+    m2 = AutoModel.from_pretrained(str(tmp_path), trust_remote_code=True, torch_dtype=torch.bfloat16)
+    assert type(m2).__name__ == "CoDALanguageModel" and hasattr(m2, "diffusion_generate")
+    assert m2.lm_head.weight.dtype == torch.bfloat16
+    assert torch.equal(m2.lm_head.weight.float(), m.lm_head.weight.to(torch.bfloat16).float())
+
+
+def test_no_cpu_fallback_and_argument_errors():
+    from coda_amd._lib import CodaHipError
+    cfg, m = _tiny_model()
+    ids = torch.zeros(1, 4, dtype=torch.long)
+    with pytest.raises(CodaHipError):
+        m(ids)
+    with pytest.raises(CodaHipError):
+        m.diffusion_generate(ids, max_new_tokens=8, steps=4, alg="entropy")
+    with pytest.raises(ValueError):
+        m.diffusion_generate(torch.zeros(1, 40, dtype=torch.long), max_length=20, steps=4, alg="entropy")
+    with pytest.raises(AssertionError):
+        m.diffusion_generate(None, max_new_tokens=8)
+    with pytest.raises(RuntimeError, match="Unknown alg"):
+        m.diffusion_generate(ids, max_new_tokens=8, steps=4, alg="bogus")
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(ids)
+
+
+def test_window_plan_and_schedule_match_oracle():
+    from coda_amd.generation_utils import plan_windows, fp32_schedule
+    from oracle import ref_cpu
+    assert plan_windows(128, 256, 128, 32) == (8, 32, 16)
+    assert plan_windows(128, 256, 128, None) == (1, 256, 128)
+    assert plan_windows(128, 256, 128, 256) == (1, 256, 128)
+    with pytest.raises(ValueError):
+        plan_windows(8, 100, 10, 32)
+    with pytest.raises(ValueError):
+        plan_windows(8, 64, 9, 32)
+    for G, steps in ((256, 128), (512, 32), (32, 16), (64, 32), (768, 768)):
+        ratios = fp32_schedule(steps, 1e-3)
+        m, ks = torch.tensor(G * 4), []
+        for j in range(steps):
+            nm = m / 4
+            k = int(nm) if j == steps - 1 else int(nm * torch.tensor(ratios[j]))
+            ks.append(k)
+            m = m - 4 * k
+        assert ks == ref_cpu.transfer_counts(G * 4, 4, steps, 1e-3)
+
+
+def test_shard_bounds_cover_everything():
+    from coda_amd.dp import shard_bounds
+    for n in (0, 1, 7, 32, 513):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_data_parallel_gather_gloo_world2(tmp_path):
+    """N>1 path on CPU: two gloo ranks shard 5 prompts (ragged 3+2), 'generate' with a stub, gather in order."""
+    script = tmp_path / "dp_worker.py"
+    script.write_text(f"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {ROOT!r})
+from coda_amd.dp import generate_data_parallel, gather_completions
+dist.init_process_group("gloo")
+ids = torch.arange(5 * 4).reshape(5, 4)
+gen = lambda x: torch.cat([x, x.sum(1, keepdim=True) + 100 * dist.get_rank()], dim=1)
+out = generate_data_parallel(gen, ids, dist)
+expect = torch.cat([ids, ids.sum(1, keepdim=True) + torch.tensor([0, 0, 0, 100, 100])[:, None]], dim=1)
+assert torch.equal(out, expect), out
+m = gather_completions(torch.full((1, 2), dist.get_rank()), dist)
+assert m.tolist() == [[0, 0], [1, 1]]
+dist.destroy_process_group()
+print("rank ok")
+""")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("rank ok") == 2
