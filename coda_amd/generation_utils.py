@@ -175,6 +175,7 @@ class DLMGenerationMixin:
         logits_hook = kwargs.pop("generation_logits_hook_func", None)
         attention_mask = kwargs.pop("attention_mask", None)
         noise_source = kwargs.pop("noise_source", None)
+        self._debug_trace = kwargs.pop("debug_trace", None)     # list: receives per-step device confidences (tests)
         had_max_length_kwarg = kwargs.get("max_length") is not None
         generation_config = self._prepare_generation_config(generation_config, **kwargs)
 
@@ -272,6 +273,9 @@ class DLMGenerationMixin:
                     rows = rows.float()
                 eng.confidence_from_logits(rows.contiguous(), alg_id, temperature, top_p, top_k, tok_noise, seed, round_conf)
 
+            if getattr(self, "_debug_trace", None) is not None:
+                self._debug_trace.append(dict(step=i, conf=eng.conf.clone(), x0=eng.x0.clone(), count=eng.count.clone(),
+                                              dst=eng.dst_pos.clone(), lo=lo, hi=hi))
             if alg == "origin":
                 eng.origin_transfer(x, cap, u, p_transfer)
             else:

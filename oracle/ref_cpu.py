@@ -209,8 +209,10 @@ def top_k_filter(logits: torch.Tensor, top_k: int) -> torch.Tensor:
 
 
 def sample_tokens(logits: torch.Tensor, temperature: float = 0.0, top_p=None, top_k=None,
-                  margin: bool = False, neg_entropy: bool = False, noise=None, step: int = 0):
-    """Returns (confidence[N], x0[N]) for rows of logits [N, V]."""
+                  margin: bool = False, neg_entropy: bool = False, noise=None, step: int = 0, diag=None):
+    """Returns (confidence[N], x0[N]) for rows of logits [N, V].  ``diag`` (a dict) receives
+    'gap': the relative distance between the winning and the runner-up token of every row (used by
+    parity tests to tell a genuine near-tie from a wrong answer)."""
     if temperature > 0:
         logits = logits / temperature
     if top_p is not None and top_p < 1:
@@ -223,8 +225,19 @@ def sample_tokens(logits: torch.Tensor, temperature: float = 0.0, top_p=None, to
         q = noise.token_exp(step, probs)
         x0 = (probs / q).argmax(dim=-1)
         conf = probs.gather(-1, x0[:, None]).squeeze(-1)
+        if diag is not None and probs.shape[0]:
+            t2 = torch.topk((probs / q).float(), 2, dim=-1)[0]
+            diag["gap"] = (t2[:, 0] - t2[:, 1]) / t2[:, 0].clamp_min(1e-30)
     else:
         conf, x0 = probs.max(dim=-1)
+        if diag is not None and probs.shape[0]:
+            t2 = torch.topk(logits.float(), 2, dim=-1)[0]
+            diag["gap"] = (t2[:, 0] - t2[:, 1]) / t2[:, 0].abs().clamp_min(1e-30)
+    if diag is not None and probs.shape[0]:
+        live = logits.float()
+        live = live.masked_fill(live <= torch.finfo(logits.dtype).min, 0.0)     # entries removed by top-p / top-k
+        diag["absmax"] = live.abs().max(dim=-1)[0]
+        diag["pmax"] = probs.float().max(dim=-1)[0]
     if margin:
         top2 = torch.sort(probs, dim=-1, descending=True)[0][:, :2]
         conf = top2[:, 0] - top2[:, 1]
@@ -271,6 +284,13 @@ class SamplerTrace:
     x0: List[torch.Tensor] = field(default_factory=list)
     k: List[int] = field(default_factory=list)
     chosen: List[torch.Tensor] = field(default_factory=list)
+    # per step: selection key [B, L] (confidence, or softmax(conf/alg_temp)/noise; -inf off-candidate),
+    # candidate mask [B, L] and the relative top-2 gap of every candidate's token choice
+    key: List[torch.Tensor] = field(default_factory=list)
+    cand: List[torch.Tensor] = field(default_factory=list)
+    gap: List[torch.Tensor] = field(default_factory=list)
+    absmax: List[torch.Tensor] = field(default_factory=list)     # largest |logit| of every candidate row
+    pmax: List[torch.Tensor] = field(default_factory=list)       # largest probability of every candidate row
 
 
 def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.Tensor,
@@ -320,28 +340,36 @@ def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: to
             p_transfer = 1 - s / t if not last else 1
             x0 = torch.full((rows.shape[0],), args.mask_id, dtype=torch.long)
             pick = noise.origin_uniform(i, rows.shape[0]) < p_transfer
-            _, x0[pick] = sample_tokens(rows[pick], args.temperature, args.top_p, args.top_k, noise=noise, step=i)
+            dg = {} if trace else None
+            _, x0[pick] = sample_tokens(rows[pick], args.temperature, args.top_p, args.top_k, noise=noise, step=i, diag=dg)
             x[mask_index] = x0.clone()
             if trace:
-                tr.x0.append(x0.clone())
+                gap = torch.full((rows.shape[0],), float("inf"))
+                if "gap" in dg:
+                    gap[pick] = dg["gap"]
+                tr.x0.append(x0.clone()); tr.gap.append(gap); tr.cand.append(mask_index.clone())
+                tr.key.append(None); tr.k.append(None); tr.absmax.append(None); tr.conf.append(None); tr.pmax.append(None)
         else:
             if args.alg not in ("maskgit_plus", "topk_margin", "entropy"):
                 raise RuntimeError(f"Unknown alg: {args.alg}")
+            dg = {} if trace else None
             conf, x0 = sample_tokens(rows, args.temperature, args.top_p, args.top_k,
                                      margin=args.alg == "topk_margin", neg_entropy=args.alg == "entropy",
-                                     noise=noise, step=i)
+                                     noise=noise, step=i, diag=dg)
             n_mask = mask_index.sum() / mask_index.shape[0]
             k = int(n_mask * (1 - s / t)) if not last else int(n_mask)
             full = torch.full(x.shape, -torch.inf, dtype=logits.dtype)
             full[mask_index] = conf
             chosen = torch.zeros((0, 2), dtype=torch.long)
+            sel_key = full
             if k > 0:
                 if args.alg_temp is None or args.alg_temp == 0:
                     _, idx = torch.topk(full, k)
                 else:
                     pr = F.softmax(full / args.alg_temp, dim=-1)
                     q = noise.select_exp(i, pr)
-                    _, idx = torch.topk(pr / q, k)      # == torch.multinomial(pr, k) without replacement
+                    sel_key = pr / q
+                    _, idx = torch.topk(sel_key, k)     # == torch.multinomial(pr, k) without replacement
                 cand = torch.full_like(x, args.mask_id)
                 cand[mask_index] = x0.clone()
                 r = torch.arange(B)[:, None].expand_as(idx)
@@ -349,6 +377,9 @@ def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: to
                 chosen = torch.stack([r.reshape(-1), idx.reshape(-1)], dim=1)
             if trace:
                 tr.conf.append(conf.clone()); tr.x0.append(x0.clone()); tr.k.append(k); tr.chosen.append(chosen)
+                tr.key.append(sel_key.float().masked_fill(~mask_index, -torch.inf)); tr.cand.append(mask_index.clone())
+                tr.gap.append(dg.get("gap", torch.zeros(0))); tr.absmax.append(dg.get("absmax", torch.zeros(0)))
+                tr.pmax.append(dg.get("pmax", torch.zeros(0)))
         if tokens_hook is not None:
             x = tokens_hook(i, x, logits)
         if args.output_history or trace:

@@ -8,6 +8,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

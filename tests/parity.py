@@ -1,0 +1,141 @@
+"""Teacher-forced parity analysis shared by the GPU tests and smoke().
+
+The HIP path and the oracle are compared step by step FROM THE SAME STATE (the oracle is restarted
+from the HIP path's x at every step), so one near-tie cannot cascade.  Per step:
+
+  tokens       x0 of every candidate equals the oracle's, except where the oracle's own winner /
+               runner-up distance is inside the declared near-tie band: greedy - top-2 logits within
+               BAND_TOK (two bf16 ulps, relative); sampling - the two best race keys p/q within
+               e^u - 1, u = what two bf16 ulps of the row's largest logit become after the division by
+               the temperature (token_band()).
+  confidence   for candidates whose token agrees, |conf_hip - conf_oracle| <= conf_tolerance(...):
+               what a two-ulp change of the row's largest bf16 logit does to the confidence, plus
+               the oracle's own bf16 rounding of the confidence.  (Logits are bf16 in the reference;
+               one ulp of a logit of magnitude 8..16 is 0.0625, i.e. ~6 % on a probability.)
+  selection    given the HIP path's OWN confidences, the revealed positions must be exactly the
+               reference rule (top-k, or top-k of softmax(conf/alg_temp)/noise; ties -> lowest index)
+               and k must equal the reference's fp32 schedule.  (L0: integer logic is exact.)
+Anything else is a violation."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_cpu
+
+BAND_TOK = 2.0 ** -6      # two bf16 ulps, relative, on the top-2 logits (or race keys) of a row
+
+
+def bf16_ulp(x: torch.Tensor) -> torch.Tensor:
+    return torch.exp2(torch.floor(torch.log2(x.abs().clamp_min(1e-30))) - 7)
+
+
+def token_band(absmax: torch.Tensor, temperature: float) -> torch.Tensor:
+    if temperature <= 0:
+        return torch.full_like(absmax, BAND_TOK)
+    u = bf16_ulp(absmax) * 2.0 / temperature + bf16_ulp(absmax) * 2.0
+    return torch.expm1(u)
+
+
+def conf_tolerance(conf_o: torch.Tensor, absmax: torch.Tensor, pmax: torch.Tensor, alg: str, temperature: float) -> torch.Tensor:
+    """|conf_hip - conf_oracle| bound: a two-ulp move of the row's largest bf16 logit (before and, if sampling,
+    after the bf16 division by the temperature) scales probabilities by e^u; the oracle additionally rounds
+    probabilities (and their difference / entropy sum) to bf16."""
+    u = bf16_ulp(absmax) * 2.0
+    if temperature > 0:
+        u = u / temperature + bf16_ulp(absmax) * 2.0
+    grow = torch.expm1(u)
+    if alg == "entropy":
+        base = conf_o.abs() + 1.0
+    elif alg == "topk_margin":
+        base = 2.0 * pmax                         # p1 - p2: both terms move, both are bf16-rounded in the oracle
+    else:
+        base = conf_o.abs()
+    return (grow + 2.0 ** -7) * base + 1e-4
+
+
+def teacher_forced(sd, d, ids, hip_hist, hip_trace, noise_log=None, **kw):
+    G = kw["max_new_tokens"]
+    alg, alg_temp, temperature = kw["alg"], kw.get("alg_temp") or 0.0, kw.get("temperature") or 0.0
+    x_init = F.pad(ids, (0, G), value=d.mask_id)
+    states = [x_init] + list(hip_hist[:-1])
+    noise = ref_cpu.ReplayNoise(noise_log) if noise_log is not None else None
+    tr = ref_cpu.diffusion_generate(sd, d, ids, force_states=states, trace=True, noise=noise, **kw)
+    sel_noise = {s: t for k_, s, t in (noise_log or []) if k_ == "select"}
+    st = dict(steps=len(hip_hist), exact_steps=0, candidates=0, band_tok=0, conf_checked=0, max_conf_err=0.0,
+              max_conf_err_over_tol=0.0, violations=[])
+    B, L = x_init.shape
+    for i, new in enumerate(hip_hist):
+        prev, cand = states[i], tr.cand[i]
+        if torch.equal(tr.history[i], new):
+            st["exact_steps"] += 1
+        n = int(cand.sum())
+        st["candidates"] += n
+        ht = hip_trace[i]
+        if int(ht["count"].item()) != n:
+            st["violations"].append((i, f"candidate count {int(ht['count'].item())} != {n}"))
+            continue
+        flat = cand.reshape(-1).nonzero().squeeze(1)
+        if not torch.equal(ht["dst"][:n].long().cpu(), flat):
+            st["violations"].append((i, "candidate order differs"))
+            continue
+        conf_h = ht["conf"].cpu()[flat]
+        x0_h = ht["x0"].cpu()[flat]
+        x0_o = tr.x0[i]
+        if alg == "origin":
+            picked = x0_o != d.mask_id                      # the oracle only samples the transferred rows
+            gap = tr.gap[i]
+            tok_bad = picked & (x0_h != x0_o)
+            band = torch.full_like(gap, BAND_TOK) if temperature <= 0 else torch.full_like(gap, math.expm1(4 * 0.125 / temperature))
+            st["band_tok"] += int((tok_bad & (gap <= band)).sum())
+            if (tok_bad & (gap > band)).any():
+                st["violations"].append((i, f"token differs outside band, gaps {gap[tok_bad].tolist()}"))
+            expect = prev.clone().reshape(-1)
+            expect[flat[picked]] = x0_h[picked]
+            if not torch.equal(expect.reshape(B, L), new):
+                st["violations"].append((i, "origin transfer set differs"))
+            continue
+        # ---- tokens
+        gap = tr.gap[i]
+        tok_bad = x0_h != x0_o
+        band = token_band(tr.absmax[i], temperature)
+        st["band_tok"] += int((tok_bad & (gap <= band)).sum())
+        if (tok_bad & (gap > band)).any():
+            st["violations"].append((i, f"token differs outside band, gaps {gap[tok_bad & (gap > band)].tolist()}"))
+        # ---- confidences (only where the token agrees: with sampling the confidence is p[x0])
+        ok = ~tok_bad
+        conf_o = tr.conf[i].float()
+        tol = conf_tolerance(conf_o, tr.absmax[i], tr.pmax[i], alg, temperature)
+        err = (conf_h - conf_o).abs()
+        if ok.any():
+            st["conf_checked"] += int(ok.sum())
+            st["max_conf_err"] = max(st["max_conf_err"], float(err[ok].max()))
+            st["max_conf_err_over_tol"] = max(st["max_conf_err_over_tol"], float((err[ok] / tol[ok]).max()))
+            if (err[ok] > tol[ok]).any():
+                j = int((err / tol).masked_fill(~ok, 0).argmax())
+                st["violations"].append((i, f"confidence outside tolerance: hip {conf_h[j]:.6g} oracle {conf_o[j]:.6g} tol {tol[j]:.3g}"))
+        # ---- selection, exact, from the HIP path's own confidences
+        k = tr.k[i]
+        full = torch.full((B * L,), -torch.inf)
+        full[flat] = conf_h
+        full = full.reshape(B, L)
+        key = full
+        if alg_temp > 0:
+            key = torch.softmax(full / alg_temp, -1) / sel_noise[i].float()
+            key = key.masked_fill(~cand, -torch.inf)
+        expect = prev.clone()
+        x0_full = torch.full((B * L,), -1, dtype=torch.long)
+        x0_full[flat] = x0_h
+        x0_full = x0_full.reshape(B, L)
+        near = False
+        for b in range(B):
+            pos = cand[b].nonzero().squeeze(1).tolist()
+            order = sorted(pos, key=lambda p: (-float(key[b, p]), p))[:max(k, 0)]
+            expect[b, order] = x0_full[b, order]
+            if 0 < k < len(pos):
+                srt = sorted((float(key[b, p]) for p in pos), reverse=True)
+                if abs(srt[k - 1] - srt[k]) <= 1e-5 * max(abs(srt[k - 1]), 1e-30):
+                    near = True
+        if not torch.equal(expect, new) and not near:
+            st["violations"].append((i, f"selection differs from the reference rule on the HIP confidences (k={k})"))
+    return st, tr
