@@ -90,8 +90,10 @@ __global__ __launch_bounds__(256) void lmhead_partial_kernel(LmArgs a) {
     const bool sampled = a.temperature > 0.f;
     const int tok = lane & 15, fq = (lane >> 4) * 4;
 
-    // row blocks beyond LM_GRID (huge candidate counts) are walked by striding
-    for (int unit = blockIdx.x; unit < active_rb * vsplits; unit += LM_GRID) {
+    // Units that share a vocab split (same weight rows, different row blocks) are consecutive; the
+    // XCD remap keeps them on one XCD so the weight tile is fetched into that L2 once, not once per
+    // row block.  Row blocks beyond LM_GRID (huge candidate counts) are walked by striding.
+    for (int unit = xcd_remap(blockIdx.x, LM_GRID); unit < active_rb * vsplits; unit += LM_GRID) {
         const int rb = unit % active_rb, vs = unit / active_rb;
         const int t_begin = (int)((long long)vs * tiles_total / vsplits);
         const int t_end = (int)((long long)(vs + 1) * tiles_total / vsplits);
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(256) void lmhead_partial_kernel(LmArgs a) {
     }
 }
 
+// One wave per candidate row: lanes stride over the vocab splits, then a shuffle tree merges them.
 __global__ __launch_bounds__(256) void lmhead_combine_kernel(const float* __restrict__ part, const int* __restrict__ count,
                                                              const int* __restrict__ dst_pos, int V, int alg, int sampled,
                                                              int round_bf16_conf, float* __restrict__ conf,
@@ -208,22 +211,29 @@ __global__ __launch_bounds__(256) void lmhead_combine_kernel(const float* __rest
     const int tiles_total = (V + BN - 1) / BN;
     int active_rb, vsplits;
     split_geometry(n, tiles_total, active_rb, vsplits);
-    for (int cand = blockIdx.x * blockDim.x + threadIdx.x; cand < n; cand += gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63;
+    const int waves = gridDim.x * (blockDim.x >> 6);
+    for (int cand = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); cand < n; cand += waves) {
         Stat s = stat_init();
-        for (int vs = 0; vs < vsplits; ++vs) {
-            const float* p = part + ((size_t)vs * active_rb * BM + cand) * PART_FLOATS;
-            Stat t{p[0], p[1], p[2], p[3], __float_as_int(p[4]), p[5], p[6], __float_as_int(p[7])};
+        for (int vs = lane; vs < vsplits; vs += 64) {
+            const f32x4_t* p = (const f32x4_t*)(part + ((size_t)vs * active_rb * BM + cand) * PART_FLOATS);
+            const f32x4_t a = p[0], b = p[1];
+            Stat t{a[0], a[1], a[2], a[3], __float_as_int(b[0]), b[1], b[2], __float_as_int(b[3])};
             s = stat_merge(s, t);
         }
-        float c;
-        const float pmax = sampled ? __expf(s.bl - s.m1) / s.Z : 1.0f / s.Z;
-        if (alg == CODA_ALG_TOPK_MARGIN) c = (1.0f - __expf(s.m2 - s.m1)) / s.Z;
-        else if (alg == CODA_ALG_ENTROPY) c = s.S / s.Z - __logf(s.Z);
-        else c = pmax;
-        if (round_bf16_conf) c = round_bf16(c);
-        const int at = dst_pos[cand];
-        conf[at] = c;
-        x0[at] = sampled ? s.barg : s.arg;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s = stat_merge(s, stat_shfl_xor(s, o));
+        if (lane == 0) {
+            float c;
+            const float pmax = sampled ? __expf(s.bl - s.m1) / s.Z : 1.0f / s.Z;
+            if (alg == CODA_ALG_TOPK_MARGIN) c = (1.0f - __expf(s.m2 - s.m1)) / s.Z;
+            else if (alg == CODA_ALG_ENTROPY) c = s.S / s.Z - __logf(s.Z);
+            else c = pmax;
+            if (round_bf16_conf) c = round_bf16(c);
+            const int at = dst_pos[cand];
+            conf[at] = c;
+            x0[at] = sampled ? s.barg : s.arg;
+        }
     }
 }
 
@@ -263,7 +273,7 @@ extern "C" int coda_lmhead_confidence(const void* hidden, long long ld_hidden, c
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(lmhead_partial_kernel, dim3(LM_GRID), dim3(256), LDS_BYTES, s, a);
     CODA_CHECK_LAUNCH("lmhead_partial");
-    const int cgrid = min(256, (max_rows + 255) / 256);
+    const int cgrid = max(1, min(2048, (max_rows + 3) / 4));
     hipLaunchKernelGGL(lmhead_combine_kernel, dim3(cgrid), dim3(256), 0, s, (const float*)workspace, count, dst_pos, V, alg,
                        temperature > 0.f ? 1 : 0, round_conf_bf16, conf, x0);
     CODA_CHECK_LAUNCH("lmhead_combine");

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Reduces rocprofv3 output (gpurun_out/prof/{kt,pmc_fetch,pmc_write}) to the summaries committed under profiles/.
+
+  python tools/summarize_prof.py r01
+
+HBM traffic follows MI355X_MICROARCH.md (HBM / rocprofv3 section): separate --pmc passes for FETCH_SIZE and
+WRITE_SIZE (KiB units); on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) coalesced
+read stream, so the read side is doubled; WRITE_SIZE is exact for 16-B/8-B streaming stores."""
+import csv
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "prof")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "")
+    return name.split("(")[0].replace("void ", "")
+
+
+rows = list(csv.DictReader(open(os.path.join(src, "kt", "kt_kernel_stats.csv"))))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
+    f.write("kernel,calls,total_ms,avg_us,min_us,max_us,percent\n")
+    for r in rows:
+        if float(r["TotalDurationNs"]) / tot < 1e-4:
+            continue
+        f.write(f"{short(r['Name'])},{r['Calls']},{float(r['TotalDurationNs'])/1e6:.3f},{float(r['AverageNs'])/1e3:.2f},"
+                f"{float(r['MinNs'])/1e3:.2f},{float(r['MaxNs'])/1e3:.2f},{100*float(r['TotalDurationNs'])/tot:.2f}\n")
+print(f"kernel stats: {len(rows)} kernels, {tot/1e6:.1f} ms total")
+
+
+def counter_avg(path, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            if r["Counter_Name"] != counter:
+                continue
+            key = short(r["Kernel_Name"]) + "|grid=" + r["Grid_Size"]
+            acc[key][0] += float(r["Counter_Value"])
+            acc[key][1] += 1
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
+
+
+traffic = {}
+fp = os.path.join(src, "pmc_fetch", "f_counter_collection.csv")
+wp = os.path.join(src, "pmc_write", "w_counter_collection.csv")
+if os.path.exists(fp) and os.path.exists(wp):
+    fetch, write = counter_avg(fp, "FETCH_SIZE"), counter_avg(wp, "WRITE_SIZE")
+    with open(os.path.join(dst, f"{tag}_hbm_traffic.csv"), "w") as f:
+        f.write("kernel|grid,launches,FETCH_SIZE_KiB_avg,WRITE_SIZE_KiB_avg,read_bytes_corrected(x2),write_bytes,hbm_bytes_per_launch\n")
+        for k in sorted(fetch, key=lambda k: -fetch[k][0] * fetch[k][1]):
+            if not (k.startswith("gemm") or k.startswith("flash") or k.startswith("lmhead") or k.startswith("rmsnorm")
+                    or k.startswith("qknorm") or k.startswith("confidence") or k.startswith("select") or k.startswith("build")
+                    or k.startswith("embed")):
+                continue
+            fk, n = fetch[k]
+            wk = write.get(k, (0.0, 0))[0]
+            rb, wb = fk * 1024 * 2, wk * 1024
+            traffic[k] = rb + wb
+            f.write(f"{k},{n},{fk:.1f},{wk:.1f},{rb:.0f},{wb:.0f},{rb+wb:.0f}\n")
+    gate_up = [v for k, v in traffic.items() if k.startswith("gemm_bf16_kernel<2>")]
+    out = {"source": f"profiles/{tag}_hbm_traffic.csv", "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB->bytes, per launch"}
+    if gate_up:
+        out["gate_up_hbm_bytes_per_launch"] = max(gate_up)
+    json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    print("traffic:", {k: f"{v/1e6:.1f} MB" for k, v in list(traffic.items())[:12]})
