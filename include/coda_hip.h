@@ -57,6 +57,10 @@ int coda_rmsnorm(const void* x, long long ldx, const void* weight, void* out, lo
 int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, const void* W, long long ldw, void* C,
                    long long ldc, const void* R, long long ldr, int M, int N, int K, int epilogue, void* stream);
 
+/* Tuning/diagnostic knob: which tile engine coda_gemm_bf16 uses (0 = automatic choice by shape,
+ * 1 = 128x128 engine, 2 = 256x256 engine).  Results are identical up to fp32 summation order. */
+int coda_gemm_select(int variant);
+
 /* q_norm / k_norm + rotary embedding, in place on the fused QKV activation.
  * Replaces modeling_coda.py:128-148 and modeling_utils.py:70-101.
  * qkv bf16 [T, (n_q + 2 n_kv) * 128]: q heads, then k heads, then v heads (v untouched).

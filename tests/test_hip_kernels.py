@@ -66,6 +66,48 @@ def test_gemm_exact_integer(M, N, K):
     assert torch.equal(out, ref.to(BF))
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("M,N,K,epi", [(512, 512, 64, "f32"), (768, 256, 192, "plain"), (300, 520, 128, "f32"),
+                                       (1024, 768, 2048, "res"), (515, 512, 320, "res")])
+def test_gemm_engines_exact_integer(variant, M, N, K, epi):
+    """Both tile engines (128x128 and 256x256, forced through coda_gemm_select) on exact integer data."""
+    lib = _lib.load()
+    assert lib.coda_gemm_select(variant) == 0
+    try:
+        X, W = int_mat((M, K), -3, 3, 21), int_mat((N, K), -2, 2, 22)
+        ref = X.float() @ W.float().t()
+        assert ref.abs().max() < 2 ** 24
+        if epi == "f32":
+            assert torch.equal(gemm(X.to(DEV), W.to(DEV), _lib.EPI_F32).cpu(), ref)
+        elif epi == "plain":
+            assert torch.equal(gemm(X.to(DEV), W.to(DEV), _lib.EPI_PLAIN).cpu(), ref.to(BF))
+        else:
+            R = int_mat((M, N), -50, 50, 23)
+            want = (ref.to(BF).float() + R.float()).to(BF)
+            assert torch.equal(gemm(X.to(DEV), W.to(DEV), _lib.EPI_RESIDUAL, R=R.to(DEV)).cpu(), want)
+    finally:
+        lib.coda_gemm_select(0)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_gemm_engines_swiglu(variant):
+    from coda_amd.engine import interleave_gate_up
+    lib = _lib.load()
+    lib.coda_gemm_select(variant)
+    try:
+        M, I, K = 520, 384, 256
+        Wg, Wu = int_mat((I, K), -1, 1, 31), int_mat((I, K), -2, 2, 32)
+        X = int_mat((M, K), -1, 1, 33)
+        gate, up = (X.float() @ Wg.float().t()).to(BF), (X.float() @ Wu.float().t()).to(BF)
+        ref = torch.nn.functional.silu(gate) * up
+        out = gemm(X.to(DEV), interleave_gate_up(Wg, Wu).to(DEV), _lib.EPI_SWIGLU).cpu()
+        # integer operands: gate/up are exact, only silu's exp differs between host and device libm
+        assert (out.float() - ref.float()).abs().max() <= 2.0 ** -7 * ref.float().abs().max()
+        assert (out == ref).float().mean() > 0.99
+    finally:
+        lib.coda_gemm_select(0)
+
+
 def test_gemm_identity_asymmetric():
     K = 128
     X = torch.eye(K).to(BF)
