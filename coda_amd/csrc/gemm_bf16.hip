@@ -108,46 +108,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// 256x256 engine (gemm_tile256.h): same epilogues, no row gather.
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-
-    const int nwg = a.tiles_m * a.tiles_n;
-    const int id = xcd_remap(blockIdx.x, nwg);
-    constexpr int GROUP_M = 4;
-    const int per_group = GROUP_M * a.tiles_n;
-    const int g = id / per_group;
-    const int gm0 = g * GROUP_M;
-    const int gsz = min(a.tiles_m - gm0, GROUP_M);
-    const int tm = gm0 + (id % per_group) % gsz;
-    const int tn = (id % per_group) / gsz;
-    const int m0 = tm * tile256::BM, n0 = tn * tile256::BN;
-
-    tile256::Src src;
-    src.xbase = a.X;
-    src.wbase = a.W;
-    const int ch = tile256::dma_chunk(lane) * 16;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = tile256::dma_row(i, wave, lane);
-        const int gm = min(m0 + r, a.M - 1);
-        const int gn = min(n0 + r, a.N - 1);
-        src.xoff[i] = (unsigned)((size_t)gm * a.ldx_bytes + ch);
-        src.woff[i] = (unsigned)((size_t)gn * a.ldw_bytes + ch);
-    }
-
-    f32x4_t acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    tile256::mainloop(src, a.K, lds, wave, lane, acc);
-
+__device__ __forceinline__ void epilogue256(const GemmArgs& a, const f32x4_t (&acc)[4][8], int m0, int n0, int wm, int wn, int lane) {
     const int tok = lane & 15, fq = (lane >> 4) * 4;
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
@@ -194,6 +156,49 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256x256 engine (gemm_tile256.h): same epilogues, no row gather.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int nwg = a.tiles_m * a.tiles_n;
+    const int id = xcd_remap(blockIdx.x, nwg);
+    constexpr int GROUP_M = 4;
+    const int per_group = GROUP_M * a.tiles_n;
+    const int g = id / per_group;
+    const int gm0 = g * GROUP_M;
+    const int gsz = min(a.tiles_m - gm0, GROUP_M);
+    const int tm = gm0 + (id % per_group) % gsz;
+    const int tn = (id % per_group) / gsz;
+    const int m0 = tm * tile256::BM, n0 = tn * tile256::BN;
+
+    tile256::Src src;
+    src.xbase = a.X;
+    src.wbase = a.W;
+    const int ch = tile256::dma_chunk(lane) * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = tile256::dma_row(i, wave, lane);
+        const int gm = min(m0 + r, a.M - 1);
+        const int gn = min(n0 + r, a.N - 1);
+        src.xoff[i] = (unsigned)((size_t)gm * a.ldx_bytes + ch);
+        src.woff[i] = (unsigned)((size_t)gn * a.ldw_bytes + ch);
+    }
+
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    tile256::mainloop(src, a.K, lds, wave, lane, acc);
+
+    epilogue256<EPI>(a, acc, m0, n0, wm, wn, lane);
+}
+
 template <int EPI>
 static int launch256(GemmArgs a, hipStream_t s) {
     static bool attr_done = false;
@@ -210,9 +215,142 @@ static int launch256(GemmArgs a, hipStream_t s) {
     return CODA_OK;
 }
 
-static int g_gemm_variant = 0;   // 0 auto, 1 force 128x128 engine, 2 force 256x256 engine
+
+// ---------------------------------------------------------------------------------------------
+// Persistent 256x256 engine: one workgroup per CU walks its output tiles; the LDS ring, the
+// LDS-DMA stream and the fragment prefetch run CONTINUOUSLY across output-tile boundaries, so the
+// first K tiles of the next output tile are already landing while the current tile's epilogue
+// stores - no per-tile prologue bubble (worth ~8 % at K = 2048).
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
+    namespace T = tile256;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntiles = a.tiles_m * a.tiles_n;
+    const int G = gridDim.x;
+    const int slot = xcd_remap(blockIdx.x, G);
+    const int nk = a.K / T::BK;
+    constexpr int GROUP_M = 4;
+    const int per_group = GROUP_M * a.tiles_n;
+    auto coords = [&](int L, int& m0, int& n0) {
+        const int g = L / per_group, gm0 = g * GROUP_M;
+        const int gsz = min(a.tiles_m - gm0, GROUP_M);
+        m0 = (gm0 + (L % per_group) % gsz) * T::BM;
+        n0 = ((L % per_group) / gsz) * T::BN;
+    };
+    T::Src src;
+    src.xbase = a.X;
+    src.wbase = a.W;
+    const int ch = T::dma_chunk(lane) * 16;
+    auto make_src = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = T::dma_row(i, wave, lane);
+            src.xoff[i] = (unsigned)((size_t)min(m0 + r, a.M - 1) * a.ldx_bytes + ch);
+            src.woff[i] = (unsigned)((size_t)min(n0 + r, a.N - 1) * a.ldw_bytes + ch);
+        }
+    };
+
+    int Lc = slot;
+    if (Lc >= ntiles) return;
+    int cm0, cn0;
+    coords(Lc, cm0, cn0);
+    make_src(cm0, cn0);
+    int dL = Lc, dk = 0;                     // DMA cursor: the next K tile to T::stage is (dL, dk)
+    auto dma_next = [&](char* dst) {
+        if (dL < ntiles) {
+            T::stage(src, (size_t)dk * T::BK * 2, dst, wave);
+            if (++dk == nk) {
+                dk = 0;
+                dL += G;
+                if (dL < ntiles) {
+                    int m0, n0;
+                    coords(dL, m0, n0);
+                    make_src(m0, n0);
+                }
+            }
+        }
+    };
+    dma_next(lds);
+    dma_next(lds + T::STAGE_BYTES);
+    T::tile_sync();
+
+    const int r16 = lane & 15, kq = lane >> 4, sw = lane & 7;
+    const int p0 = ((0 * 4 + kq) ^ sw) * 16, p1 = ((1 * 4 + kq) ^ sw) * 16;
+    const char* xs = lds + (wm * 128 + r16) * 128;
+    const char* ws = lds + T::OP_BYTES + (wn * 64 + r16) * 128;
+    T::Frags f;
+    T::load_w<0, 0>(f, ws, p0);
+    T::load_x<0, 0>(f, xs, p0);
+
+    constexpr int EPI_VMEM = (EPI == EPI_SWIGLU) ? 16 : 32;   // stores one wave issues per full tile
+    int cur = 0;                              // byte offset of the LDS T::stage holding the current K tile
+    bool stores_in_flight = false;            // previous tile's epilogue was the unconditional (full-tile) one
+    for (; Lc < ntiles; Lc += G) {
+        coords(Lc, cm0, cn0);
+        f32x4_t acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < nk; ++t) {
+            const int nxt = T::STAGE_BYTES - cur;
+            const char* xc = xs + cur;
+            const char* wc = ws + cur;
+            T::phase_begin(); T::load_w<1, 1>(f, wc, p0); T::quad<0, 0, 0, 0>(f, acc);
+            T::phase_begin(); T::load_x<1, 1>(f, xc, p0); T::quad<1, 0, 1, 0>(f, acc);
+            T::phase_begin(); T::load_x<0, 0>(f, xc, p1); T::quad<1, 1, 1, 1>(f, acc);
+            T::phase_begin(); T::load_w<1, 1>(f, wc, p1); T::quad<0, 1, 0, 1>(f, acc);
+            T::phase_begin(); T::load_w<0, 0>(f, wc, p1); T::quad<1, 0, 1, 0>(f, acc);
+            T::phase_begin(); T::load_x<1, 1>(f, xc, p1); T::quad<0, 0, 0, 0>(f, acc);
+            // every wave has retired its reads of this T::stage; the next K tile of the stream (DMA issued one
+            // K tile ago, i.e. older than any epilogue store still in flight) has landed
+            if (stores_in_flight && t == 0) {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(EPI_VMEM) : "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                T::tile_sync();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            dma_next(lds + cur);
+            T::load_x<0, 0>(f, xs + nxt, p0);       // first fragments of the next K tile (stale bytes after the last one: unused)
+            T::quad<0, 1, 0, 1>(f, acc);
+            T::phase_begin();
+            T::load_w<0, 0>(f, ws + nxt, p0);
+            T::quad<1, 1, 1, 1>(f, acc);
+            cur = nxt;
+        }
+        const bool full = cm0 + T::BM <= a.M && cn0 + T::BN <= a.N;
+        epilogue256<EPI>(a, acc, cm0, cn0, wm, wn, lane);
+        stores_in_flight = full;
+    }
+}
+
+template <int EPI>
+static int launch256p(GemmArgs a, hipStream_t s) {
+    static bool attr_done = false;
+    static int n_cu = 256;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)gemm256p_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                tile256::LDS_BYTES) != hipSuccess)
+            return CODA_ERR_LAUNCH;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            n_cu = cus;
+        attr_done = true;
+    }
+    a.tiles_m = (a.M + tile256::BM - 1) / tile256::BM;
+    a.tiles_n = (a.N + tile256::BN - 1) / tile256::BN;
+    const int grid = a.tiles_m * a.tiles_n < n_cu ? a.tiles_m * a.tiles_n : n_cu;
+    hipLaunchKernelGGL(gemm256p_bf16_kernel<EPI>, dim3(grid), dim3(512), tile256::LDS_BYTES, s, a);
+    CODA_CHECK_LAUNCH("gemm256p_bf16");
+    return CODA_OK;
+}
+
+static int g_gemm_variant = 0;   // 0 auto, 1 force 128x128, 2 force 256x256 (one tile per workgroup), 3 force persistent 256x256
 extern "C" int coda_gemm_select(int variant) {
-    if (variant < 0 || variant > 2) return CODA_ERR_ARG;
+    if (variant < 0 || variant > 3) return CODA_ERR_ARG;
     g_gemm_variant = variant;
     return CODA_OK;
 }
@@ -222,7 +360,7 @@ static bool use_tile256(const GemmArgs& a) {
     // per-lane 32-bit DMA offsets: the operand panels of one launch must span < 4 GiB
     if ((size_t)a.M * a.ldx_bytes >= 0xffffffffull || (size_t)a.N * a.ldw_bytes >= 0xffffffffull) return false;
     if (g_gemm_variant == 1) return false;
-    if (g_gemm_variant == 2) return true;
+    if (g_gemm_variant >= 2) return true;
     const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     // one 512-thread workgroup per CU: want whole waves of 256 tiles without a long tail
     const long rounds = (tiles + 255) / 256;
@@ -261,6 +399,15 @@ extern "C" int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, c
     a.M = M; a.N = N; a.K = K;
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
     hipStream_t s = (hipStream_t)stream;
+    if (use_tile256(a) && g_gemm_variant != 2) {
+        switch (epilogue) {
+            case EPI_PLAIN: return launch256p<EPI_PLAIN>(a, s);
+            case EPI_RESIDUAL: return launch256p<EPI_RESIDUAL>(a, s);
+            case EPI_SWIGLU: return launch256p<EPI_SWIGLU>(a, s);
+            case EPI_F32: return launch256p<EPI_F32>(a, s);
+            default: return CODA_ERR_ARG;
+        }
+    }
     if (use_tile256(a)) {
         switch (epilogue) {
             case EPI_PLAIN: return launch256<EPI_PLAIN>(a, s);
