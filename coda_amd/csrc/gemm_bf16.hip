@@ -3,6 +3,7 @@
 // plus the ops fused behind them: residual add (:247,:253) and SiLU(gate)*up (:59).
 #include "gemm_tile128.h"
 #include "gemm_tile256.h"
+#include "gemm_tile256x128.h"
 #include "coda_abi_internal.h"
 
 using namespace tile128;
@@ -348,23 +349,218 @@ static int launch256p(GemmArgs a, hipStream_t s) {
     return CODA_OK;
 }
 
-static int g_gemm_variant = 0;   // 0 auto, 1 force 128x128, 2 force 256x256 (one tile per workgroup), 3 force persistent 256x256
+
+// ---------------------------------------------------------------------------------------------
+// Persistent 256x128 engine (gemm_tile256x128.h) for the N = 2048 projections.
+template <int EPI>
+__device__ __forceinline__ void epilogue256x128(const GemmArgs& a, const f32x4_t (&acc)[4][4], int m0, int n0, int wm, int wn, int lane) {
+    const int tok = lane & 15, fq = (lane >> 4) * 4;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wm * 64 + mt * 16 + tok;
+        if (m >= a.M) continue;
+        if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int n = (n0 + wn * 64) / 2 + p * 16 + fq;
+                if (n >= a.N / 2) continue;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gte = round_bf16(acc[2 * p][mt][r]);
+                    const float up = round_bf16(acc[2 * p + 1][mt][r]);
+                    o[r] = round_bf16(silu_f32(gte)) * up;
+                }
+                u32x2_t v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                *(u32x2_t*)(a.C + (size_t)m * a.ldc_bytes + (size_t)n * 2) = v;
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = n0 + wn * 64 + nt * 16 + fq;
+                if (n >= a.N) continue;
+                if constexpr (EPI == EPI_F32) {
+                    *(f32x4_t*)(a.C + (size_t)m * a.ldc_bytes + (size_t)n * 4) = acc[nt][mt];
+                } else {
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = acc[nt][mt][r];
+                    if constexpr (EPI == EPI_RESIDUAL) {
+                        const u32x2_t rv = *(const u32x2_t*)(a.R + (size_t)m * a.ldr_bytes + (size_t)n * 2);
+                        o[0] = round_bf16(o[0]) + bf16_bits_to_f32(rv[0] & 0xffff);
+                        o[1] = round_bf16(o[1]) + bf16_bits_to_f32(rv[0] >> 16);
+                        o[2] = round_bf16(o[2]) + bf16_bits_to_f32(rv[1] & 0xffff);
+                        o[3] = round_bf16(o[3]) + bf16_bits_to_f32(rv[1] >> 16);
+                    }
+                    u32x2_t v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                    *(u32x2_t*)(a.C + (size_t)m * a.ldc_bytes + (size_t)n * 2) = v;
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256x128p_bf16_kernel(GemmArgs a) {
+    namespace T = tile256x128;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = a.tiles_m * a.tiles_n;
+    const int G = gridDim.x;
+    const int slot = xcd_remap(blockIdx.x, G);
+    const int nk = a.K / T::BK;
+    constexpr int GROUP_M = 4;
+    const int per_group = GROUP_M * a.tiles_n;
+    auto coords = [&](int L, int& m0, int& n0) {
+        const int g = L / per_group, gm0 = g * GROUP_M;
+        const int gsz = min(a.tiles_m - gm0, GROUP_M);
+        m0 = (gm0 + (L % per_group) % gsz) * T::BM;
+        n0 = ((L % per_group) / gsz) * T::BN;
+    };
+    T::Src src;
+    src.xbase = a.X;
+    src.wbase = a.W;
+    const int ch = tile256::dma_chunk(lane) * 16;
+    auto make_src = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            src.xoff[i] = (unsigned)((size_t)min(m0 + tile256::dma_row(i, wave, lane), a.M - 1) * a.ldx_bytes + ch);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            src.woff[i] = (unsigned)((size_t)min(n0 + tile256::dma_row(i, wave, lane), a.N - 1) * a.ldw_bytes + ch);
+    };
+
+    int Lc = slot;
+    if (Lc >= ntiles) return;
+    int cm0, cn0;
+    coords(Lc, cm0, cn0);
+    make_src(cm0, cn0);
+    int dL = Lc, dk = 0;
+    auto dma_next = [&](char* dst) {
+        if (dL < ntiles) {
+            T::stage(src, (size_t)dk * T::BK * 2, dst, wave);
+            if (++dk == nk) {
+                dk = 0;
+                dL += G;
+                if (dL < ntiles) {
+                    int m0, n0;
+                    coords(dL, m0, n0);
+                    make_src(m0, n0);
+                }
+            }
+        }
+    };
+    // 3-stage ring: the DMA of K tile q+3 is issued at the sync of tile q, so two K tiles (~1 us of MFMA
+    // work) are in flight ahead of the one being multiplied - enough to cover an HBM miss.
+    int issued = 0;                           // K tiles staged so far (wave-uniform)
+    for (int i = 0; i < 3; ++i) {
+        const bool had = dL < ntiles;
+        dma_next(lds + i * T::STAGE_BYTES);
+        issued += had ? 1 : 0;
+    }
+    if (issued >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (issued == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int r16 = lane & 15, kq = lane >> 4, sw = lane & 7;
+    const int p0 = ((0 * 4 + kq) ^ sw) * 16, p1 = ((1 * 4 + kq) ^ sw) * 16;
+    const char* xs = lds + (wm * 64 + r16) * 128;
+    const char* ws = lds + T::X_BYTES + (wn * 64 + r16) * 128;
+    T::Frags f;
+    T::load_w<0, 0>(f, ws, p0);
+    T::load_x<0>(f, xs, p0);
+
+    constexpr int EPI_VMEM = (EPI == EPI_SWIGLU) ? 8 : 16;
+    int cur = 0, q = 0;                       // LDS byte offset of the current stage; stream position
+    bool stores_in_flight = false;
+    for (; Lc < ntiles; Lc += G) {
+        coords(Lc, cm0, cn0);
+        f32x4_t acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < nk; ++t) {
+            const int nxt = cur == 2 * T::STAGE_BYTES ? 0 : cur + T::STAGE_BYTES;
+            const char* xc = xs + cur;
+            const char* wc = ws + cur;
+            T::phase_begin(); T::load_w<1, 1>(f, wc, p0); T::half<0, 0, 0>(f, acc);
+            T::phase_begin(); T::load_x<1>(f, xc, p1); T::load_w<0, 0>(f, wc, p1); T::half<1, 0, 1>(f, acc);
+            T::phase_begin(); T::load_w<1, 1>(f, wc, p1); T::half<0, 1, 0>(f, acc);
+            // need K tile q+1 landed; tile q+2 (6 DMA instructions per wave) and the previous output tile's
+            // epilogue stores may stay in flight (both are younger than tile q+1's DMA)
+            {
+                const bool ahead = issued > q + 2;
+                const bool st = stores_in_flight && t == 0;
+                if (ahead && st) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(EPI_VMEM + 6) : "memory");
+                else if (ahead) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                else if (st) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(EPI_VMEM) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const bool had = dL < ntiles;
+                dma_next(lds + cur);
+                issued += had ? 1 : 0;
+            }
+            ++q;
+            T::load_x<0>(f, xs + nxt, p0);
+            T::load_w<0, 0>(f, ws + nxt, p0);
+            T::half<1, 1, 1>(f, acc);
+            cur = nxt;
+        }
+        const bool full = cm0 + T::BM <= a.M && cn0 + T::BN <= a.N;
+        epilogue256x128<EPI>(a, acc, cm0, cn0, wm, wn, lane);
+        stores_in_flight = full;
+    }
+}
+
+template <int EPI>
+static int launch256x128p(GemmArgs a, hipStream_t s) {
+    static bool attr_done = false;
+    static int n_cu = 256;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)gemm256x128p_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                tile256x128::LDS_BYTES) != hipSuccess)
+            return CODA_ERR_LAUNCH;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            n_cu = cus;
+        attr_done = true;
+    }
+    a.tiles_m = (a.M + tile256x128::BM - 1) / tile256x128::BM;
+    a.tiles_n = (a.N + tile256x128::BN - 1) / tile256x128::BN;
+    const int grid = a.tiles_m * a.tiles_n < n_cu ? a.tiles_m * a.tiles_n : n_cu;
+    hipLaunchKernelGGL(gemm256x128p_bf16_kernel<EPI>, dim3(grid), dim3(512), tile256x128::LDS_BYTES, s, a);
+    CODA_CHECK_LAUNCH("gemm256x128p_bf16");
+    return CODA_OK;
+}
+
+static int g_gemm_variant = 0;   // 0 auto, 1 force 128x128, 2 force 256x256 (one tile per workgroup), 3 force persistent 256x256, 4 force persistent 256x128
 extern "C" int coda_gemm_select(int variant) {
-    if (variant < 0 || variant > 3) return CODA_ERR_ARG;
+    if (variant < 0 || variant > 4) return CODA_ERR_ARG;
     g_gemm_variant = variant;
     return CODA_OK;
 }
 
-static bool use_tile256(const GemmArgs& a) {
-    if (a.x_rows) return false;
+// -> 0: 128x128 engine, 2: 256x256 one tile per workgroup, 3: persistent 256x256, 4: persistent 256x128
+static int pick_engine(const GemmArgs& a) {
+    if (a.x_rows) return 0;
     // per-lane 32-bit DMA offsets: the operand panels of one launch must span < 4 GiB
-    if ((size_t)a.M * a.ldx_bytes >= 0xffffffffull || (size_t)a.N * a.ldw_bytes >= 0xffffffffull) return false;
-    if (g_gemm_variant == 1) return false;
-    if (g_gemm_variant >= 2) return true;
-    const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    // one 512-thread workgroup per CU: want whole waves of 256 tiles without a long tail
-    const long rounds = (tiles + 255) / 256;
-    return a.M >= 256 && a.N >= 256 && tiles >= 200 && (double)tiles / (double)(rounds * 256) >= 0.85;
+    if ((size_t)a.M * a.ldx_bytes >= 0xffffffffull || (size_t)a.N * a.ldw_bytes >= 0xffffffffull) return 0;
+    if (g_gemm_variant == 1) return 0;
+    if (g_gemm_variant >= 2) return g_gemm_variant;
+    if (a.M < 256 || a.N < 128) return 0;
+    // one 512-thread workgroup per CU: prefer the engine whose tile count fills whole rounds of 256 CUs
+    auto fill = [](long tiles) { const long rounds = (tiles + 255) / 256; return (double)tiles / (double)(rounds * 256); };
+    const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const long t128 = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
+    if (a.N >= 256 && t256 >= 200 && fill(t256) >= 0.85) return 3;
+    if (t128 >= 200 && fill(t128) >= 0.85) return 4;
+    return 0;
 }
 
 template <int EPI>
@@ -399,24 +595,19 @@ extern "C" int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, c
     a.M = M; a.N = N; a.K = K;
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
     hipStream_t s = (hipStream_t)stream;
-    if (use_tile256(a) && g_gemm_variant != 2) {
-        switch (epilogue) {
-            case EPI_PLAIN: return launch256p<EPI_PLAIN>(a, s);
-            case EPI_RESIDUAL: return launch256p<EPI_RESIDUAL>(a, s);
-            case EPI_SWIGLU: return launch256p<EPI_SWIGLU>(a, s);
-            case EPI_F32: return launch256p<EPI_F32>(a, s);
-            default: return CODA_ERR_ARG;
-        }
+    const int engine = pick_engine(a);
+#define CODA_DISPATCH(fn)                                      \
+    switch (epilogue) {                                        \
+        case EPI_PLAIN: return fn<EPI_PLAIN>(a, s);            \
+        case EPI_RESIDUAL: return fn<EPI_RESIDUAL>(a, s);      \
+        case EPI_SWIGLU: return fn<EPI_SWIGLU>(a, s);          \
+        case EPI_F32: return fn<EPI_F32>(a, s);                \
+        default: return CODA_ERR_ARG;                          \
     }
-    if (use_tile256(a)) {
-        switch (epilogue) {
-            case EPI_PLAIN: return launch256<EPI_PLAIN>(a, s);
-            case EPI_RESIDUAL: return launch256<EPI_RESIDUAL>(a, s);
-            case EPI_SWIGLU: return launch256<EPI_SWIGLU>(a, s);
-            case EPI_F32: return launch256<EPI_F32>(a, s);
-            default: return CODA_ERR_ARG;
-        }
-    }
+    if (engine == 4) { CODA_DISPATCH(launch256x128p) }
+    if (engine == 3) { CODA_DISPATCH(launch256p) }
+    if (engine == 2) { CODA_DISPATCH(launch256) }
+#undef CODA_DISPATCH
     switch (epilogue) {
         case EPI_PLAIN: return launch<EPI_PLAIN>(a, s);
         case EPI_RESIDUAL: return launch<EPI_RESIDUAL>(a, s);

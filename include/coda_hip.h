@@ -58,7 +58,7 @@ int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, const void* 
                    long long ldc, const void* R, long long ldr, int M, int N, int K, int epilogue, void* stream);
 
 /* Tuning/diagnostic knob: which tile engine coda_gemm_bf16 uses (0 = automatic choice by shape,
- * 1 = 128x128 engine, 2 = 256x256 engine with one tile per workgroup, 3 = persistent 256x256 engine).  Results are identical up to fp32 summation order. */
+ * 1 = 128x128 engine, 2 = 256x256 engine with one tile per workgroup, 3 = persistent 256x256 engine, 4 = persistent 256x128 engine).  Results are identical up to fp32 summation order. */
 int coda_gemm_select(int variant);
 
 /* q_norm / k_norm + rotary embedding, in place on the fused QKV activation.
