@@ -16,6 +16,7 @@
 // LDS image for both K and V tiles: 64 rows x 256 B, 16-B chunk ch of row r stored at chunk
 // ch ^ (((r&3)<<2) | ((r>>2)&3)): conflict-free for the b128 row reads and the transposed reads.
 #include "coda_abi_internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -23,6 +24,7 @@ constexpr int QB = 128;      // queries per workgroup
 constexpr int KB = 64;       // keys per tile
 constexpr int TILE = KB * 256;                 // 16 KiB
 constexpr int ATTN_LDS = 4 * TILE;             // K[2] + V[2]
+constexpr float RESCALE_THR = 6.0f;            // log2 units: P <= 64 between rescales
 
 struct AttnArgs {
     const char* qkv; long long ld_b;
@@ -33,7 +35,7 @@ struct AttnArgs {
 
 __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
-__global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -85,32 +87,73 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a) {
     const int v_chunk0 = 2 * ((lane >> 4) & 1) + (tp >> 1);
     const int v_byte = 8 * (tp & 1);
 
-    const int nt = (L + KB - 1) / KB;
-    stage(0, 0);
-    for (int t = 0; t < nt; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+    // loop-invariant LDS byte offsets (relative to the K / V tile base)
+    //  K fragment (k2, ks): row 32 k2 + c, 16-B chunk 2 ks + h
+    int k_off[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) k_off[k2] = (32 * k2 + c) * 256;
+    const int k_sw = swz(c);                      // swz(32 k2 + c) == swz(c): only row bits 0..3 enter
+    //  V fragment (st, jj): rows 16 st + 8 jj + 4 h + tq; chunk 4 db + v_chunk0
+    int v_off[4][2], v_sw[4][2];
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int row = 16 * st + 8 * jj + 4 * h + tq;
+            v_off[st][jj] = row * 256 + v_byte;
+            v_sw[st][jj] = swz(row);
+        }
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+    auto lgkm0 = [] {
+        __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto load_k = [&](const char* kt, int k2, int half, bf16x8_t (&kf)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kf[j] = *(const bf16x8_t*)(kt + k_off[k2] + (((2 * (4 * half + j) + h) ^ k_sw) << 4));
+    };
+    auto load_v = [&](const char* vt, int st, bf16x8_t (&vf)[4]) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const s16x4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (CODA_LDS s16x4_t*)(vt + v_off[st][0] + (((4 * db + v_chunk0) ^ v_sw[st][0]) << 4)));
+            const s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (CODA_LDS s16x4_t*)(vt + v_off[st][1] + (((4 * db + v_chunk0) ^ v_sw[st][1]) << 4)));
+            const s16x8_t v8 = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+            vf[db] = __builtin_bit_cast(bf16x8_t, v8);
+        }
+    };
+
+    // One K/V tile.  Fragment reads are issued one batch ahead of the MFMAs that consume them
+    // (register double buffers kA/kB, vA/vB); MASK is only instantiated for a ragged last tile.
+    auto tile = [&](int t, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
         const char* kt = lds + (t & 1) * TILE;
         const char* vt = lds + (2 + (t & 1)) * TILE;
-
-        // ---- S^T = K Q^T : two 32-key sub-tiles
+        bf16x8_t kA[4], kB[4], vA[4], vB[4];
         f32x16_t s[2];
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
+        for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[k2][i] = 0.f;
-            const int row = 32 * k2 + c;
-            const char* rp = kt + row * 256;
-            const int sw = swz(row);
+
+        // ---- S^T = K Q^T : two 32-key sub-tiles, four batches of 4 k-steps
+        load_k(kt, 0, 0, kA);
+        lgkm0(); load_k(kt, 0, 1, kB);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8_t kf = *(const bf16x8_t*)(rp + (((2 * ks + h) ^ sw) << 4));
-                s[k2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[k2], 0, 0, 0);
-            }
-        }
-        // ---- mask keys beyond L (last tile only)
-        if ((t + 1) * KB > L) {
+        for (int j = 0; j < 4; ++j) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[j], qf[j], s[0], 0, 0, 0);
+        lgkm0(); load_k(kt, 1, 0, kA);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kB[j], qf[4 + j], s[0], 0, 0, 0);
+        lgkm0(); load_k(kt, 1, 1, kB);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[j], qf[j], s[1], 0, 0, 0);
+        lgkm0(); load_v(vt, 0, vA);                 // first V batch flies under the last QK MFMAs and the softmax
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kB[j], qf[4 + j], s[1], 0, 0, 0);
+
+        if constexpr (MASK) {
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
@@ -119,57 +162,68 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnArgs a) {
                     if (key >= L) s[k2][i] = -1e30f;
                 }
         }
-        // ---- online softmax (per query = per lane column; the two halves hold disjoint keys)
+        // ---- online softmax in the log2 domain (per query = per lane column; the two halves hold disjoint keys).
+        // Deferred rescale: the running maximum (and with it the O accumulator) is only moved when some row's
+        // maximum grew by more than RESCALE_THR; until then P is bounded by 2^RESCALE_THR instead of 1, which
+        // bf16 P and the fp32 sums tolerate.
         float mx = s[0][0];
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
             for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[k2][i]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f((m_run - m_new) * a.scale_log2e);
-        const float mb = m_new * a.scale_log2e;
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * a.scale_log2e;
+        if (__any(mx > m_run + RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // 0 on the first tile (m_run = -1e30)
+            l_run *= alpha;
+            m_run = m_new;
+            if (t > 0) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+            }
+        }
         float psum = 0.f;
+        const float neg_m = -m_run;
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float p = exp2f(s[k2][i] * a.scale_log2e - mb);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[k2][i], a.scale_log2e, neg_m));
                 s[k2][i] = p;
                 psum += p;
             }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+        l_run += psum;
 
-        // ---- O^T += V^T P^T : 4 k-steps of 16 keys, 4 d-blocks of 32
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
+        // ---- O^T += V^T P^T : 4 k-steps of 16 keys x 4 d-blocks of 32
+        auto pv = [&](int st, const bf16x8_t (&vf)[4]) {
             const int k2 = st >> 1, r0 = 8 * (st & 1);
             bf16x8_t pf;
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[k2][r0 + j];
 #pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                s16x4_t lo4, hi4;
-                {
-                    const int row = 32 * k2 + 16 * (st & 1) + 4 * h + tq;            // jj = 0
-                    const int off = row * 256 + (((4 * db + v_chunk0) ^ swz(row)) << 4) + v_byte;
-                    lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((CODA_LDS s16x4_t*)(vt + off));
-                }
-                {
-                    const int row = 32 * k2 + 16 * (st & 1) + 8 + 4 * h + tq;        // jj = 1
-                    const int off = row * 256 + (((4 * db + v_chunk0) ^ swz(row)) << 4) + v_byte;
-                    hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((CODA_LDS s16x4_t*)(vt + off));
-                }
-                typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-                const s16x8_t v8 = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, v8), pf, oacc[db], 0, 0, 0);
-            }
-        }
+            for (int db = 0; db < 4; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db], pf, oacc[db], 0, 0, 0);
+        };
+        lgkm0(); load_v(vt, 1, vB); pv(0, vA);
+        lgkm0(); load_v(vt, 2, vA); pv(1, vB);
+        lgkm0(); load_v(vt, 3, vB); pv(2, vA);
+        lgkm0(); pv(3, vB);
+    };
+
+    const int nt = (L + KB - 1) / KB;
+    const int n_full = L / KB;                     // tiles without a ragged edge
+    stage(0, 0);
+    for (int t = 0; t < n_full; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+        tile(t, std::false_type{});
+    }
+    if (n_full < nt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        tile(n_full, std::true_type{});
     }
 
     // ---- epilogue: normalise, store bf16.  reg i of d-block db: d = 32 db + (i&3) + 8 (i>>2) + 4 h

@@ -8,7 +8,7 @@
 
 using namespace tile128;
 
-enum { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_F32 = 3 };
+enum { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_F32 = 3, EPI_QKROPE = 4 };
 
 struct GemmArgs {
     const char* X; long long ldx_bytes; const int* x_rows;   // x_rows: optional row gather (nullable)
@@ -17,6 +17,9 @@ struct GemmArgs {
     const char* R; long long ldr_bytes;
     int M, N, K;
     int tiles_m, tiles_n;
+    // EPI_QKROPE only: q/k RMSNorm weights, rotary tables [L,128], sequence length, feature bounds of q and q|k
+    const char* qn_w; const char* kn_w; const char* rope_cos; const char* rope_sin;
+    int L, q_feat, qk_feat; float eps;
 };
 
 __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + __expf(-x)); }
@@ -217,6 +220,75 @@ static int launch256(GemmArgs a, hipStream_t s) {
 }
 
 
+// Fused q_norm / k_norm + rotary epilogue of the QKV projection (modeling_coda.py:128-148,
+// modeling_utils.py:70-101) for the persistent 256x256 engine.  The weight rows of every q/k head are
+// stored permuted as [0..31, 64..95, 32..63, 96..127], so the wave that owns 64 of the head's 128
+// features holds, in accumulator pairs (nt, nt+2), exactly the (j, j+64) partners RoPE rotates;
+// the RMS over the head's 128 features needs one 128-float exchange with the partner wave (LDS).
+// V tiles take the plain epilogue.  Rounding points follow the reference's bf16 op sequence.
+__device__ __forceinline__ void epilogue256_qkrope(const GemmArgs& a, f32x4_t (&acc)[4][8], int m0, int n0, int wm, int wn,
+                                                   int wave, int lane, float* xch) {
+    if (n0 >= a.qk_feat) {                    // V columns: tile-uniform branch
+        epilogue256<EPI_PLAIN>(a, acc, m0, n0, wm, wn, lane);
+        return;
+    }
+    const int tok = lane & 15, fq = (lane >> 4) * 4;
+    const int feat0 = n0 + (wn >> 1) * 128;   // first feature of this wave's head in the output row
+    const int qh = wn & 1;
+    const char* nw = feat0 < a.q_feat ? a.qn_w : a.kn_w;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        float t = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = round_bf16(acc[nt][mt][r]);
+                acc[nt][mt][r] = x;
+                t += x * x;
+            }
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        if ((lane >> 4) == 0) xch[wave * 128 + mt * 16 + tok] = t;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const int m = m0 + wm * 128 + mt * 16 + tok;
+        const float tot = xch[wave * 128 + mt * 16 + tok] + xch[(wave ^ 1) * 128 + mt * 16 + tok];
+        if (m >= a.M) continue;
+        const float inv = 1.0f / sqrtf(tot * (1.0f / 128.0f) + a.eps);
+        const int pos = m % a.L;
+        char* orow = a.C + (size_t)m * a.ldc_bytes + (size_t)feat0 * 2;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int j = 32 * qh + nt * 16 + fq;
+            const u32x2_t cv = *(const u32x2_t*)(a.rope_cos + ((size_t)pos * 128 + j) * 2);
+            const u32x2_t sv = *(const u32x2_t*)(a.rope_sin + ((size_t)pos * 128 + j) * 2);
+            const float c[4] = {bf16_bits_to_f32(cv[0] & 0xffff), bf16_bits_to_f32(cv[0] >> 16), bf16_bits_to_f32(cv[1] & 0xffff),
+                                bf16_bits_to_f32(cv[1] >> 16)};
+            const float sn[4] = {bf16_bits_to_f32(sv[0] & 0xffff), bf16_bits_to_f32(sv[0] >> 16), bf16_bits_to_f32(sv[1] & 0xffff),
+                                 bf16_bits_to_f32(sv[1] >> 16)};
+            const u32x2_t a1 = *(const u32x2_t*)(nw + j * 2), a2 = *(const u32x2_t*)(nw + (j + 64) * 2);   // L1-resident
+            const float w1[4] = {bf16_bits_to_f32(a1[0] & 0xffff), bf16_bits_to_f32(a1[0] >> 16), bf16_bits_to_f32(a1[1] & 0xffff),
+                                 bf16_bits_to_f32(a1[1] >> 16)};
+            const float w2[4] = {bf16_bits_to_f32(a2[0] & 0xffff), bf16_bits_to_f32(a2[0] >> 16), bf16_bits_to_f32(a2[1] & 0xffff),
+                                 bf16_bits_to_f32(a2[1] >> 16)};
+            float o1[4], o2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float n1 = round_bf16(w1[r] * round_bf16(acc[nt][mt][r] * inv));
+                const float n2 = round_bf16(w2[r] * round_bf16(acc[nt + 2][mt][r] * inv));
+                o1[r] = round_bf16(n1 * c[r]) - round_bf16(n2 * sn[r]);      // first half: x1 cos + (-x2) sin
+                o2[r] = round_bf16(n2 * c[r]) + round_bf16(n1 * sn[r]);      // second half: x2 cos + x1 sin
+            }
+            *(u32x2_t*)(orow + j * 2) = (u32x2_t){pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3])};
+            *(u32x2_t*)(orow + (j + 64) * 2) = (u32x2_t){pack_bf16x2(o2[0], o2[1]), pack_bf16x2(o2[2], o2[3])};
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Persistent 256x256 engine: one workgroup per CU walks its output tiles; the LDS ring, the
 // LDS-DMA stream and the fragment prefetch run CONTINUOUSLY across output-tile boundaries, so the
@@ -323,7 +395,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
             cur = nxt;
         }
         const bool full = cm0 + T::BM <= a.M && cn0 + T::BN <= a.N;
-        epilogue256<EPI>(a, acc, cm0, cn0, wm, wn, lane);
+        if constexpr (EPI == EPI_QKROPE) epilogue256_qkrope(a, acc, cm0, cn0, wm, wn, wave, lane, (float*)(lds + T::LDS_BYTES));
+        else epilogue256<EPI>(a, acc, cm0, cn0, wm, wn, lane);
         stores_in_flight = full;
     }
 }
@@ -334,7 +407,7 @@ static int launch256p(GemmArgs a, hipStream_t s) {
     static int n_cu = 256;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)gemm256p_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                tile256::LDS_BYTES) != hipSuccess)
+                                tile256::LDS_BYTES + 4096) != hipSuccess)
             return CODA_ERR_LAUNCH;
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
@@ -344,7 +417,7 @@ static int launch256p(GemmArgs a, hipStream_t s) {
     a.tiles_m = (a.M + tile256::BM - 1) / tile256::BM;
     a.tiles_n = (a.N + tile256::BN - 1) / tile256::BN;
     const int grid = a.tiles_m * a.tiles_n < n_cu ? a.tiles_m * a.tiles_n : n_cu;
-    hipLaunchKernelGGL(gemm256p_bf16_kernel<EPI>, dim3(grid), dim3(512), tile256::LDS_BYTES, s, a);
+    hipLaunchKernelGGL(gemm256p_bf16_kernel<EPI>, dim3(grid), dim3(512), tile256::LDS_BYTES + (EPI == EPI_QKROPE ? 4096 : 0), s, a);
     CODA_CHECK_LAUNCH("gemm256p_bf16");
     return CODA_OK;
 }
@@ -587,7 +660,7 @@ extern "C" int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, c
     if (((uintptr_t)X | (uintptr_t)W) & 15 || (ldx * 2) % 16 || (ldw * 2) % 16) return CODA_ERR_ALIGN;
     if (((uintptr_t)C) & (4 * esz - 1) || (ldc * esz) % (4 * esz)) return CODA_ERR_ALIGN;
     if (R && ((((uintptr_t)R) & 7) || (ldr * 2) % 8)) return CODA_ERR_ALIGN;
-    GemmArgs a;
+    GemmArgs a{};
     a.X = (const char*)X; a.ldx_bytes = ldx * 2; a.x_rows = x_rows;
     a.W = (const char*)W; a.ldw_bytes = ldw * 2;
     a.C = (char*)C; a.ldc_bytes = ldc * esz;
@@ -615,4 +688,30 @@ extern "C" int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, c
         case EPI_F32: return launch<EPI_F32>(a, s);
         default: return CODA_ERR_ARG;
     }
+}
+
+
+// QKV projection with the q/k RMSNorm + rotary embedding fused into the epilogue (one launch instead of
+// coda_gemm_bf16 + coda_qknorm_rope).  W must be packed with coda_amd.engine.permute_qk_rows.
+extern "C" int coda_qkv_proj_rope(const void* X, long long ldx, const void* W, long long ldw, void* qkv, long long ld,
+                                  const void* q_weight, const void* k_weight, const void* cos, const void* sin, int T, int L,
+                                  int n_q, int n_kv, int K, float eps, void* stream) {
+    const int N = (n_q + 2 * n_kv) * 128;
+    if (T < 256 || L <= 0 || T % L || n_q <= 0 || n_kv <= 0 || K <= 0 || K % 64) return CODA_ERR_SHAPE;
+    if ((n_q * 128) % 256 || (n_kv * 128) % 256 || ld < N) return CODA_ERR_SHAPE;
+    if (!X || !W || !qkv || !q_weight || !k_weight || !cos || !sin) return CODA_ERR_ARG;
+    if (((uintptr_t)X | (uintptr_t)W | (uintptr_t)qkv | (uintptr_t)q_weight | (uintptr_t)k_weight | (uintptr_t)cos | (uintptr_t)sin) & 15 ||
+        (ldx * 2) % 16 || (ldw * 2) % 16 || (ld * 2) % 16)
+        return CODA_ERR_ALIGN;
+    if ((size_t)T * ldx * 2 >= 0xffffffffull || (size_t)N * ldw * 2 >= 0xffffffffull) return CODA_ERR_SHAPE;
+    GemmArgs a{};
+    a.X = (const char*)X; a.ldx_bytes = ldx * 2; a.x_rows = nullptr;
+    a.W = (const char*)W; a.ldw_bytes = ldw * 2;
+    a.C = (char*)qkv; a.ldc_bytes = ld * 2;
+    a.R = nullptr; a.ldr_bytes = 0;
+    a.M = T; a.N = N; a.K = K;
+    a.qn_w = (const char*)q_weight; a.kn_w = (const char*)k_weight;
+    a.rope_cos = (const char*)cos; a.rope_sin = (const char*)sin;
+    a.L = L; a.q_feat = n_q * 128; a.qk_feat = (n_q + n_kv) * 128; a.eps = eps;
+    return launch256p<EPI_QKROPE>(a, (hipStream_t)stream);
 }

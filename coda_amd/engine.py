@@ -34,6 +34,15 @@ def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     return torch.stack((gate.view(I // 16, 16, H), up.view(I // 16, 16, H)), dim=1).reshape(2 * I, H).contiguous()
 
 
+def permute_qk_rows(wqkv: torch.Tensor, n_q: int, n_kv: int, d: int = 128) -> torch.Tensor:
+    """Row order coda_qkv_proj_rope expects: inside every q and k head the 128 rows are stored as
+    [0..31, 64..95, 32..63, 96..127] (rotary partners j / j+64 land in one MFMA lane); v rows stay."""
+    assert d == 128
+    order = torch.cat([torch.arange(0, 32), torch.arange(64, 96), torch.arange(32, 64), torch.arange(96, 128)])
+    idx = torch.cat([h * d + order for h in range(n_q + n_kv)] + [torch.arange((n_q + n_kv) * d, (n_q + 2 * n_kv) * d)])
+    return wqkv[idx.to(wqkv.device)].contiguous()
+
+
 class HipEngine:
     """One engine per model replica (per GPU)."""
 
@@ -49,8 +58,6 @@ class HipEngine:
         self.theta = cfg.rope_theta
         if self.d != 128:
             raise _lib.CodaHipError("HIP kernels are specialised for head_dim 128")
-        if self.n_q * self.d != self.H and False:
-            pass
         if self.H % 64 or self.I % 64 or (self.n_q * self.d) % 64:
             raise _lib.CodaHipError("hidden/intermediate sizes must be multiples of 64")
         self.qkv_dim = (self.n_q + 2 * self.n_kv) * self.d
@@ -73,6 +80,11 @@ class HipEngine:
                 wo=w(p + "self_attn.o_proj.weight"),
                 wgu=interleave_gate_up(w(p + "mlp.gate_proj.weight"), w(p + "mlp.up_proj.weight")),
                 wd=w(p + "mlp.down_proj.weight")))
+        # fused QKV + q/k-norm + RoPE needs whole 256-feature tiles inside the q and the k block
+        self.fuse_qk = self.n_q % 2 == 0 and self.n_kv % 2 == 0
+        if self.fuse_qk:
+            for lw in self.lw:
+                lw["wqkv_rope"] = permute_qk_rows(lw["wqkv"], self.n_q, self.n_kv, self.d)
         self._shape = None
         self._rope = {}
         self.timer = None          # optional KernelTimer (bench.py)
@@ -132,9 +144,18 @@ class HipEngine:
         scale = 1.0 / math.sqrt(self.d)
         for lw in self.lw:
             _lib.call("coda_rmsnorm", _ptr(self.h), self.H, _ptr(lw["n_in"]), _ptr(self.a), self.H, T, self.H, self.eps, s)
-            self._gemm("qkv", self.a, lw["wqkv"], self.qkv, _lib.EPI_PLAIN)
-            _lib.call("coda_qknorm_rope", _ptr(self.qkv), self.qkv_dim, _ptr(lw["qn"]), _ptr(lw["kn"]), _ptr(cos),
-                      _ptr(sin), T, L, self.n_q, self.n_kv, self.eps, s)
+            if self.fuse_qk and T >= 256:
+                t = self.timer
+                if t is not None:
+                    t.begin("qkv", 2.0 * T * self.qkv_dim * self.H)
+                _lib.call("coda_qkv_proj_rope", _ptr(self.a), self.H, _ptr(lw["wqkv_rope"]), self.H, _ptr(self.qkv), self.qkv_dim,
+                          _ptr(lw["qn"]), _ptr(lw["kn"]), _ptr(cos), _ptr(sin), T, L, self.n_q, self.n_kv, self.H, self.eps, s)
+                if t is not None:
+                    t.end("qkv")
+            else:
+                self._gemm("qkv", self.a, lw["wqkv"], self.qkv, _lib.EPI_PLAIN)
+                _lib.call("coda_qknorm_rope", _ptr(self.qkv), self.qkv_dim, _ptr(lw["qn"]), _ptr(lw["kn"]), _ptr(cos),
+                          _ptr(sin), T, L, self.n_q, self.n_kv, self.eps, s)
             _lib.call("coda_flash_attn_noncausal", _ptr(self.qkv), self.qkv_dim, _ptr(self.ao), self.n_q * self.d, B, L,
                       self.n_q, self.n_kv, scale, s)
             self._gemm("o_proj", self.ao, lw["wo"], self.h, _lib.EPI_RESIDUAL, R=self.h)

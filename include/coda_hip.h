@@ -69,6 +69,15 @@ int coda_gemm_select(int variant);
 int coda_qknorm_rope(void* qkv, long long ld, const void* q_weight, const void* k_weight, const void* cos,
                      const void* sin, int T, int L, int n_q, int n_kv, float eps, void* stream);
 
+/* QKV projection with q_norm / k_norm + rotary fused into the GEMM epilogue: one launch replacing
+ * coda_gemm_bf16(PLAIN) + coda_qknorm_rope (modeling_coda.py:123-148, modeling_utils.py:70-101), same results.
+ * W bf16 [(n_q+2 n_kv)*128, K]: q|k|v rows, with the 128 rows of every q and k head stored in the order
+ * [0..31, 64..95, 32..63, 96..127] (rotary partners j, j+64 then share an MFMA lane); v rows unpermuted.
+ * Requires T >= 256, n_q and n_kv even; returns CODA_ERR_SHAPE otherwise (use the two-call path). */
+int coda_qkv_proj_rope(const void* X, long long ldx, const void* W, long long ldw, void* qkv, long long ld,
+                       const void* q_weight, const void* k_weight, const void* cos, const void* sin, int T, int L, int n_q,
+                       int n_kv, int K, float eps, void* stream);
+
 /* Non-causal, mask-free GQA flash attention.  Replaces attention.py:12-90 (repeat_kv + SDPA with
  * is_causal=False and no mask).  Reads q/k/v from the fused QKV activation
  * (layout as above), writes out bf16 [T, n_q*128] (token-major, heads concatenated: what o_proj

@@ -214,6 +214,37 @@ def test_qknorm_rope():
     assert (out.float() - ref.float()).abs().max() < 0.05
 
 
+@pytest.mark.parametrize("B,L,n_q,n_kv,K", [(2, 200, 4, 2, 256), (3, 128, 2, 2, 128), (1, 300, 16, 8, 2048)])
+def test_fused_qkv_rope_equals_two_call_path(B, L, n_q, n_kv, K):
+    """coda_qkv_proj_rope (fused epilogue, permuted weight rows) vs coda_gemm_bf16 + coda_qknorm_rope."""
+    from coda_amd.engine import permute_qk_rows
+    g = torch.Generator().manual_seed(40)
+    d, T = 128, B * L
+    N = (n_q + 2 * n_kv) * d
+    X = torch.randn(T, K, generator=g).to(BF).to(DEV)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(DEV)
+    qw, kw = (1 + 0.1 * torch.randn(d, generator=g)).to(BF).to(DEV), (1 + 0.1 * torch.randn(d, generator=g)).to(BF).to(DEV)
+    cos, sin = ref_cpu.rope_tables(L, d, 1000000, BF)
+    cos, sin = cos.to(DEV), sin.to(DEV)
+    ref = gemm(X, W, _lib.EPI_PLAIN)
+    _lib.call("coda_qknorm_rope", _p(ref), N, _p(qw), _p(kw), _p(cos), _p(sin), T, L, n_q, n_kv, 1e-6, _s())
+    out = torch.full((T, N), float("nan"), device=DEV, dtype=BF)
+    Wp = permute_qk_rows(W, n_q, n_kv)
+    _lib.call("coda_qkv_proj_rope", _p(X), K, _p(Wp), K, _p(out), N, _p(qw), _p(kw), _p(cos), _p(sin), T, L, n_q, n_kv, K, 1e-6, _s())
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, (n_q + n_kv) * d:], ref[:, (n_q + n_kv) * d:])                 # V: plain projection
+    same = (out == ref).float().mean().item()
+    err = (out.float() - ref.float()).abs().max().item()
+    # identical rounding points; only the order of the 128-term sum of squares differs (rare one-ulp flips)
+    assert same > 0.995 and err < 0.05, (same, err)
+    # and against the oracle's op sequence on the same GEMM output
+    lin = gemm(X, W, _lib.EPI_PLAIN).cpu()
+    q = ref_cpu._rms(lin[:, : n_q * d].view(B, L, n_q, d), qw.cpu(), 1e-6).transpose(1, 2)
+    q = q * cos.cpu()[None, None] + ref_cpu._rot_half(q) * sin.cpu()[None, None]
+    want = q.transpose(1, 2).reshape(T, n_q * d)
+    assert (out.cpu()[:, : n_q * d] == want).float().mean() > 0.995
+
+
 @pytest.mark.parametrize("B,L,n_q,n_kv", [(1, 64, 2, 1), (2, 100, 4, 2), (1, 384, 16, 8), (1, 517, 2, 2)])
 def test_flash_attention(B, L, n_q, n_kv):
     g = torch.Generator().manual_seed(11)

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Times the flash attention kernel on the decoder's shapes (random data)."""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from coda_amd import _lib  # noqa: E402
+
+_lib.load()
+for B, L in ((32, 384), (64, 768), (8, 2048)):
+    n_q, n_kv, d = 16, 8, 128
+    T = B * L
+    torch.manual_seed(0)
+    qkv = torch.randn(T, (n_q + 2 * n_kv) * d, device="cuda").to(torch.bfloat16)
+    out = torch.empty(T, n_q * d, device="cuda", dtype=torch.bfloat16)
+
+    def run():
+        _lib.call("coda_flash_attn_noncausal", qkv.data_ptr(), qkv.stride(0), out.data_ptr(), n_q * d, B, L, n_q, n_kv,
+                  1.0 / math.sqrt(d), torch.cuda.current_stream().cuda_stream)
+    run()
+    torch.cuda.synchronize()
+    q = qkv[:L, :d].float()
+    k = qkv[:L, n_q * d:n_q * d + d].float()
+    v = qkv[:L, (n_q + n_kv) * d:(n_q + n_kv) * d + d].float()
+    ref = torch.softmax(q @ k.t() / math.sqrt(d), -1) @ v
+    err = (out[:L, :d].float() - ref).abs().max().item()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 20)
+    med = sorted(ts)[2]
+    fl = 4.0 * L * L * d * n_q * B
+    print(f"attn B={B} L={L}: {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF  max err vs fp32 {err:.2e}", flush=True)
