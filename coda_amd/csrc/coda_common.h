@@ -27,8 +27,23 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
 // value of f after a round trip through bf16 (emulates an op whose output dtype is bf16)
 __device__ __forceinline__ float round_bf16(float f) { return bf16_bits_to_f32(f32_to_bf16_bits(f)); }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+// two f32 -> one dword of two bf16 (RNE): a single v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-    return (unsigned int)f32_to_bf16_bits(lo) | ((unsigned int)f32_to_bf16_bits(hi) << 16);
+    const bf16x2_t h = __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t);
+    return __builtin_bit_cast(unsigned int, h);
+}
+
+__device__ __forceinline__ float bf16_lo(unsigned int pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned int pk) { return __uint_as_float(pk & 0xffff0000u); }
+
+// round_bf16 of two values for the price of three instructions
+__device__ __forceinline__ void round_bf16_pair(float& a, float& b) {
+    const unsigned int pk = pack_bf16x2(a, b);
+    a = bf16_lo(pk);
+    b = bf16_hi(pk);
 }
 
 // 16-byte asynchronous global -> LDS copy.  The LDS destination is wave-uniform base + lane*16.

@@ -22,7 +22,100 @@ struct GemmArgs {
     int L, q_feat, qk_feat; float eps;
 };
 
-__device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + __expf(-x)); }
+// silu on the MFMA-free tail of a tile: v_exp + v_rcp (about 1 ulp each, far below the bf16 rounding that follows)
+__device__ __forceinline__ float silu_f32(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896f));
+}
+
+// Epilogue of one wave's accumulator block acc[nt][mt] (4 x MT tiles of 16 features x 16 tokens):
+// the lane owns token (lane&15) of each 16-token group and features (lane>>4)*4..+3 of each 16-feature
+// group, i.e. 8 contiguous output bytes per (nt, mt).  FULL = the whole workgroup tile is inside the
+// matrix (no bounds tests).  Rounding points follow the reference's bf16 op sequence: the projection
+// output is rounded first, then residual add / silu / gate*up each round again.
+template <int EPI, int MT, bool FULL>
+__device__ __forceinline__ void epilogue_wave(const GemmArgs& a, const f32x4_t (&acc)[4][MT], int mrow0, int ncol0, int lane) {
+    const int tok = lane & 15, fq = (lane >> 4) * 4;
+    const int mf = mrow0 + tok;
+    const size_t rs = (size_t)16 * a.ldc_bytes;
+    if constexpr (EPI == EPI_SWIGLU) {
+        // weight rows are interleaved in blocks of 16: [gate 16 | up 16] -> even nt = gate, odd nt = up
+        const int nb = ncol0 / 2 + fq;
+        char* c = a.C + (size_t)mf * a.ldc_bytes + (size_t)nb * 2;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (!FULL && mf + mt * 16 >= a.M) continue;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                if (!FULL && nb + p * 16 >= a.N / 2) continue;
+                const unsigned g01 = pack_bf16x2(acc[2 * p][mt][0], acc[2 * p][mt][1]);
+                const unsigned g23 = pack_bf16x2(acc[2 * p][mt][2], acc[2 * p][mt][3]);
+                const unsigned u01 = pack_bf16x2(acc[2 * p + 1][mt][0], acc[2 * p + 1][mt][1]);
+                const unsigned u23 = pack_bf16x2(acc[2 * p + 1][mt][2], acc[2 * p + 1][mt][3]);
+                float s0 = silu_f32(bf16_lo(g01)), s1 = silu_f32(bf16_hi(g01));
+                float s2 = silu_f32(bf16_lo(g23)), s3 = silu_f32(bf16_hi(g23));
+                round_bf16_pair(s0, s1);
+                round_bf16_pair(s2, s3);
+                const u32x2_t v = {pack_bf16x2(s0 * bf16_lo(u01), s1 * bf16_hi(u01)), pack_bf16x2(s2 * bf16_lo(u23), s3 * bf16_hi(u23))};
+                *(u32x2_t*)(c + mt * rs + p * 32) = v;
+            }
+        }
+    } else if constexpr (EPI == EPI_F32) {
+        const int nb = ncol0 + fq;
+        char* c = a.C + (size_t)mf * a.ldc_bytes + (size_t)nb * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (!FULL && mf + mt * 16 >= a.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                if (!FULL && nb + nt * 16 >= a.N) continue;
+                *(f32x4_t*)(c + mt * rs + nt * 64) = acc[nt][mt];
+            }
+        }
+    } else {
+        const int nb = ncol0 + fq;
+        char* c = a.C + (size_t)mf * a.ldc_bytes + (size_t)nb * 2;
+        // token groups in batches of up to 4: the batch's residual loads are all issued before its first
+        // store (C may alias R: every lane reads exactly the bytes it later writes)
+        constexpr int MB = MT % 4 == 0 ? 4 : 3;
+#pragma unroll
+        for (int mb = 0; mb < MT; mb += MB) {
+            u32x2_t rv[MB][4];
+            if constexpr (EPI == EPI_RESIDUAL) {
+                const char* r = a.R + (size_t)mf * a.ldr_bytes + (size_t)nb * 2;
+                const size_t rrs = (size_t)16 * a.ldr_bytes;
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        rv[i][nt] = (u32x2_t){0u, 0u};
+                        if (FULL || (mf + (mb + i) * 16 < a.M && nb + nt * 16 < a.N)) rv[i][nt] = *(const u32x2_t*)(r + (mb + i) * rrs + nt * 32);
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int mt = mb + i;
+                if (!FULL && mf + mt * 16 >= a.M) continue;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    if (!FULL && nb + nt * 16 >= a.N) continue;
+                    unsigned v0 = pack_bf16x2(acc[nt][mt][0], acc[nt][mt][1]);
+                    unsigned v1 = pack_bf16x2(acc[nt][mt][2], acc[nt][mt][3]);
+                    if constexpr (EPI == EPI_RESIDUAL) {
+                        v0 = pack_bf16x2(bf16_lo(v0) + bf16_lo(rv[i][nt][0]), bf16_hi(v0) + bf16_hi(rv[i][nt][0]));
+                        v1 = pack_bf16x2(bf16_lo(v1) + bf16_lo(rv[i][nt][1]), bf16_hi(v1) + bf16_hi(rv[i][nt][1]));
+                    }
+                    *(u32x2_t*)(c + mt * rs + nt * 32) = (u32x2_t){v0, v1};
+                }
+            }
+        }
+    }
+}
+
+template <int EPI, int MT>
+__device__ __forceinline__ void epilogue_tile(const GemmArgs& a, const f32x4_t (&acc)[4][MT], int mrow0, int ncol0, int lane, bool full) {
+    if (full) epilogue_wave<EPI, MT, true>(a, acc, mrow0, ncol0, lane);
+    else epilogue_wave<EPI, MT, false>(a, acc, mrow0, ncol0, lane);
+}
 
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
@@ -63,102 +156,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
 
     mainloop(f, a.K, lds, wave, lane, acc);
 
-    // epilogue: lane owns token (lane&15) of each 16-token group, features (lane>>4)*4 .. +3 of each 16-feature group
-    const int tok = lane & 15, fq = (lane >> 4) * 4;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + tok;
-        if (m >= a.M) continue;
-        if constexpr (EPI == EPI_SWIGLU) {
-            // weight rows are interleaved in blocks of 16: [gate 16 | up 16] -> even nt = gate, odd nt = up
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int n = (n0 + wn * 64) / 2 + p * 16 + fq;     // output feature (of N/2)
-                if (n >= a.N / 2) continue;
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float gte = round_bf16(acc[2 * p][mt][r]);
-                    const float up = round_bf16(acc[2 * p + 1][mt][r]);
-                    o[r] = round_bf16(silu_f32(gte)) * up;
-                }
-                u32x2_t v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-                *(u32x2_t*)(a.C + (size_t)m * a.ldc_bytes + (size_t)n * 2) = v;
-            }
-        } else {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int n = n0 + wn * 64 + nt * 16 + fq;
-                if (n >= a.N) continue;
-                if constexpr (EPI == EPI_F32) {
-                    *(f32x4_t*)(a.C + (size_t)m * a.ldc_bytes + (size_t)n * 4) = acc[nt][mt];
-                } else {
-                    float o[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = acc[nt][mt][r];
-                    if constexpr (EPI == EPI_RESIDUAL) {
-                        const u32x2_t rv = *(const u32x2_t*)(a.R + (size_t)m * a.ldr_bytes + (size_t)n * 2);
-                        o[0] = round_bf16(o[0]) + bf16_bits_to_f32(rv[0] & 0xffff);
-                        o[1] = round_bf16(o[1]) + bf16_bits_to_f32(rv[0] >> 16);
-                        o[2] = round_bf16(o[2]) + bf16_bits_to_f32(rv[1] & 0xffff);
-                        o[3] = round_bf16(o[3]) + bf16_bits_to_f32(rv[1] >> 16);
-                    }
-                    u32x2_t v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-                    *(u32x2_t*)(a.C + (size_t)m * a.ldc_bytes + (size_t)n * 2) = v;
-                }
-            }
-        }
-    }
+    epilogue_tile<EPI, 4>(a, acc, m0 + wm * 64, n0 + wn * 64, lane, m0 + BM <= a.M && n0 + BN <= a.N);
 }
 
-
-template <int EPI>
-__device__ __forceinline__ void epilogue256(const GemmArgs& a, const f32x4_t (&acc)[4][8], int m0, int n0, int wm, int wn, int lane) {
-    const int tok = lane & 15, fq = (lane >> 4) * 4;
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-        const int m = m0 + wm * 128 + mt * 16 + tok;
-        if (m >= a.M) continue;
-        if constexpr (EPI == EPI_SWIGLU) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int n = (n0 + wn * 64) / 2 + p * 16 + fq;
-                if (n >= a.N / 2) continue;
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float gte = round_bf16(acc[2 * p][mt][r]);
-                    const float up = round_bf16(acc[2 * p + 1][mt][r]);
-                    o[r] = round_bf16(silu_f32(gte)) * up;
-                }
-                u32x2_t v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-                *(u32x2_t*)(a.C + (size_t)m * a.ldc_bytes + (size_t)n * 2) = v;
-            }
-        } else {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int n = n0 + wn * 64 + nt * 16 + fq;
-                if (n >= a.N) continue;
-                if constexpr (EPI == EPI_F32) {
-                    *(f32x4_t*)(a.C + (size_t)m * a.ldc_bytes + (size_t)n * 4) = acc[nt][mt];
-                } else {
-                    float o[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = acc[nt][mt][r];
-                    if constexpr (EPI == EPI_RESIDUAL) {
-                        const u32x2_t rv = *(const u32x2_t*)(a.R + (size_t)m * a.ldr_bytes + (size_t)n * 2);
-                        o[0] = round_bf16(o[0]) + bf16_bits_to_f32(rv[0] & 0xffff);
-                        o[1] = round_bf16(o[1]) + bf16_bits_to_f32(rv[0] >> 16);
-                        o[2] = round_bf16(o[2]) + bf16_bits_to_f32(rv[1] & 0xffff);
-                        o[3] = round_bf16(o[3]) + bf16_bits_to_f32(rv[1] >> 16);
-                    }
-                    u32x2_t v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-                    *(u32x2_t*)(a.C + (size_t)m * a.ldc_bytes + (size_t)n * 2) = v;
-                }
-            }
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // 256x256 engine (gemm_tile256.h): same epilogues, no row gather.
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs a) {
 
     tile256::mainloop(src, a.K, lds, wave, lane, acc);
 
-    epilogue256<EPI>(a, acc, m0, n0, wm, wn, lane);
+    epilogue_tile<EPI, 8>(a, acc, m0 + wm * 128, n0 + wn * 64, lane, m0 + tile256::BM <= a.M && n0 + tile256::BN <= a.N);
 }
 
 template <int EPI>
@@ -227,64 +227,111 @@ static int launch256(GemmArgs a, hipStream_t s) {
 // the RMS over the head's 128 features needs one 128-float exchange with the partner wave (LDS).
 // V tiles take the plain epilogue.  Rounding points follow the reference's bf16 op sequence.
 __device__ __forceinline__ void epilogue256_qkrope(const GemmArgs& a, f32x4_t (&acc)[4][8], int m0, int n0, int wm, int wn,
-                                                   int wave, int lane, float* xch) {
+                                                   int wave, int lane, float* xch, bool full) {
     if (n0 >= a.qk_feat) {                    // V columns: tile-uniform branch
-        epilogue256<EPI_PLAIN>(a, acc, m0, n0, wm, wn, lane);
+        epilogue_tile<EPI_PLAIN, 8>(a, acc, m0 + wm * 128, n0 + wn * 64, lane, full);
         return;
     }
     const int tok = lane & 15, fq = (lane >> 4) * 4;
     const int feat0 = n0 + (wn >> 1) * 128;   // first feature of this wave's head in the output row
     const int qh = wn & 1;
     const char* nw = feat0 < a.q_feat ? a.qn_w : a.kn_w;
+    // rotary rows are fetched two token groups ahead of their use (the compiler cannot hoist them over
+    // other memory operations itself); the prefetch cursor walks pos = m mod L incrementally
+    const int mf = m0 + wm * 128 + tok;
+    const bool step_pos = a.L >= 16;
+    int ppos = mf % a.L;
+    u32x2_t cq[8][2], sq[8][2];
+    auto fetch = [&](int mt) {
+        const char* crow = a.rope_cos + (size_t)ppos * 256 + (32 * qh + fq) * 2;
+        const char* srow = a.rope_sin + (size_t)ppos * 256 + (32 * qh + fq) * 2;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            cq[mt][nt] = *(const u32x2_t*)(crow + nt * 32);
+            sq[mt][nt] = *(const u32x2_t*)(srow + nt * 32);
+        }
+        if (step_pos) { ppos += 16; ppos -= ppos >= a.L ? a.L : 0; }
+        else ppos = (mf + (mt + 1) * 16) % a.L;
+    };
+    fetch(0);
+    fetch(1);
+    // pass 1: round the projection to bf16 and keep it PACKED (two values per register: frees half of the
+    // accumulator file for pass 2); partial sum of squares per token straight from the packed pairs
+    unsigned pk[4][8][2];
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
         float t = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt) {
+            pk[nt][mt][0] = pack_bf16x2(acc[nt][mt][0], acc[nt][mt][1]);
+            pk[nt][mt][1] = pack_bf16x2(acc[nt][mt][2], acc[nt][mt][3]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float x = round_bf16(acc[nt][mt][r]);
-                acc[nt][mt][r] = x;
-                t += x * x;
+            for (int h = 0; h < 2; ++h) {
+                const bf16x2_t v = __builtin_bit_cast(bf16x2_t, pk[nt][mt][h]);
+                t = __builtin_amdgcn_fdot2_f32_bf16(v, v, t, false);
             }
+        }
         t += __shfl_xor(t, 16, 64);
         t += __shfl_xor(t, 32, 64);
         if ((lane >> 4) == 0) xch[wave * 128 + mt * 16 + tok] = t;
     }
+    // norm weights of this lane's 2 x (4 + 4) features: loop-invariant over the tokens
+    float w1[2][4], w2[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int j = 32 * qh + nt * 16 + fq;
+        const u32x2_t a1 = *(const u32x2_t*)(nw + j * 2), a2 = *(const u32x2_t*)(nw + (j + 64) * 2);
+        w1[nt][0] = bf16_lo(a1[0]); w1[nt][1] = bf16_hi(a1[0]); w1[nt][2] = bf16_lo(a1[1]); w1[nt][3] = bf16_hi(a1[1]);
+        w2[nt][0] = bf16_lo(a2[0]); w2[nt][1] = bf16_hi(a2[0]); w2[nt][2] = bf16_lo(a2[1]); w2[nt][3] = bf16_hi(a2[1]);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // pass 2 keeps its packed results in registers and pass 3 stores them (vmcnt retires in order: a rotary
+    // load issued behind output stores would wait for their write acknowledgements)
+    u32x2_t outv[8][2][2];
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
-        const int m = m0 + wm * 128 + mt * 16 + tok;
         const float tot = xch[wave * 128 + mt * 16 + tok] + xch[(wave ^ 1) * 128 + mt * 16 + tok];
-        if (m >= a.M) continue;
-        const float inv = 1.0f / sqrtf(tot * (1.0f / 128.0f) + a.eps);
-        const int pos = m % a.L;
-        char* orow = a.C + (size_t)m * a.ldc_bytes + (size_t)feat0 * 2;
+        if (mt + 2 < 8) fetch(mt + 2);
+        const float inv = __builtin_amdgcn_rsqf(tot * (1.0f / 128.0f) + a.eps);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int j = 32 * qh + nt * 16 + fq;
-            const u32x2_t cv = *(const u32x2_t*)(a.rope_cos + ((size_t)pos * 128 + j) * 2);
-            const u32x2_t sv = *(const u32x2_t*)(a.rope_sin + ((size_t)pos * 128 + j) * 2);
-            const float c[4] = {bf16_bits_to_f32(cv[0] & 0xffff), bf16_bits_to_f32(cv[0] >> 16), bf16_bits_to_f32(cv[1] & 0xffff),
-                                bf16_bits_to_f32(cv[1] >> 16)};
-            const float sn[4] = {bf16_bits_to_f32(sv[0] & 0xffff), bf16_bits_to_f32(sv[0] >> 16), bf16_bits_to_f32(sv[1] & 0xffff),
-                                 bf16_bits_to_f32(sv[1] >> 16)};
-            const u32x2_t a1 = *(const u32x2_t*)(nw + j * 2), a2 = *(const u32x2_t*)(nw + (j + 64) * 2);   // L1-resident
-            const float w1[4] = {bf16_bits_to_f32(a1[0] & 0xffff), bf16_bits_to_f32(a1[0] >> 16), bf16_bits_to_f32(a1[1] & 0xffff),
-                                 bf16_bits_to_f32(a1[1] >> 16)};
-            const float w2[4] = {bf16_bits_to_f32(a2[0] & 0xffff), bf16_bits_to_f32(a2[0] >> 16), bf16_bits_to_f32(a2[1] & 0xffff),
-                                 bf16_bits_to_f32(a2[1] >> 16)};
-            float o1[4], o2[4];
+            const u32x2_t cv = cq[mt][nt], sv = sq[mt][nt];
+            const float c[4] = {bf16_lo(cv[0]), bf16_hi(cv[0]), bf16_lo(cv[1]), bf16_hi(cv[1])};
+            const float sn[4] = {bf16_lo(sv[0]), bf16_hi(sv[0]), bf16_lo(sv[1]), bf16_hi(sv[1])};
+            float n1[4], n2[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float n1 = round_bf16(w1[r] * round_bf16(acc[nt][mt][r] * inv));
-                const float n2 = round_bf16(w2[r] * round_bf16(acc[nt + 2][mt][r] * inv));
-                o1[r] = round_bf16(n1 * c[r]) - round_bf16(n2 * sn[r]);      // first half: x1 cos + (-x2) sin
-                o2[r] = round_bf16(n2 * c[r]) + round_bf16(n1 * sn[r]);      // second half: x2 cos + x1 sin
+            for (int h = 0; h < 2; ++h) {
+                n1[2 * h] = bf16_lo(pk[nt][mt][h]) * inv; n1[2 * h + 1] = bf16_hi(pk[nt][mt][h]) * inv;
+                n2[2 * h] = bf16_lo(pk[nt + 2][mt][h]) * inv; n2[2 * h + 1] = bf16_hi(pk[nt + 2][mt][h]) * inv;
             }
-            *(u32x2_t*)(orow + j * 2) = (u32x2_t){pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3])};
-            *(u32x2_t*)(orow + (j + 64) * 2) = (u32x2_t){pack_bf16x2(o2[0], o2[1]), pack_bf16x2(o2[2], o2[3])};
+            round_bf16_pair(n1[0], n1[1]); round_bf16_pair(n1[2], n1[3]);
+            round_bf16_pair(n2[0], n2[1]); round_bf16_pair(n2[2], n2[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { n1[r] *= w1[nt][r]; n2[r] *= w2[nt][r]; }
+            round_bf16_pair(n1[0], n1[1]); round_bf16_pair(n1[2], n1[3]);
+            round_bf16_pair(n2[0], n2[1]); round_bf16_pair(n2[2], n2[3]);
+            float pa[4], pb[4], pc[4], pd[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pa[r] = n1[r] * c[r]; pb[r] = n2[r] * sn[r]; pc[r] = n2[r] * c[r]; pd[r] = n1[r] * sn[r]; }
+            round_bf16_pair(pa[0], pa[1]); round_bf16_pair(pa[2], pa[3]);
+            round_bf16_pair(pb[0], pb[1]); round_bf16_pair(pb[2], pb[3]);
+            round_bf16_pair(pc[0], pc[1]); round_bf16_pair(pc[2], pc[3]);
+            round_bf16_pair(pd[0], pd[1]); round_bf16_pair(pd[2], pd[3]);
+            // first half: x1 cos + (-x2) sin; second half: x2 cos + x1 sin
+            outv[mt][nt][0] = (u32x2_t){pack_bf16x2(pa[0] - pb[0], pa[1] - pb[1]), pack_bf16x2(pa[2] - pb[2], pa[3] - pb[3])};
+            outv[mt][nt][1] = (u32x2_t){pack_bf16x2(pc[0] + pd[0], pc[1] + pd[1]), pack_bf16x2(pc[2] + pd[2], pc[3] + pd[3])};
+        }
+    }
+    char* orow = a.C + (size_t)mf * a.ldc_bytes + (size_t)(feat0 + 32 * qh + fq) * 2;
+    const size_t rs = (size_t)16 * a.ldc_bytes;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        if (!full && mf + mt * 16 >= a.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            *(u32x2_t*)(orow + mt * rs + nt * 32) = outv[mt][nt][0];
+            *(u32x2_t*)(orow + mt * rs + nt * 32 + 128) = outv[mt][nt][1];
         }
     }
 }
@@ -304,7 +351,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
     const int G = gridDim.x;
     const int slot = xcd_remap(blockIdx.x, G);
     const int nk = a.K / T::BK;
-    constexpr int GROUP_M = 4;
+    // row tiles per group of the tile walk.  The fused-QKV launch uses 3: with 4, a workgroup's tiles
+    // (slot + k*256) all fall in the same column band, so a quarter of the CUs would own nothing but the
+    // cheap V tiles; 3 rotates the column band from round to round
+    constexpr int GROUP_M = EPI == EPI_QKROPE ? 3 : 4;
     const int per_group = GROUP_M * a.tiles_n;
     auto coords = [&](int L, int& m0, int& n0) {
         const int g = L / per_group, gm0 = g * GROUP_M;
@@ -395,8 +445,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
             cur = nxt;
         }
         const bool full = cm0 + T::BM <= a.M && cn0 + T::BN <= a.N;
-        if constexpr (EPI == EPI_QKROPE) epilogue256_qkrope(a, acc, cm0, cn0, wm, wn, wave, lane, (float*)(lds + T::LDS_BYTES));
-        else epilogue256<EPI>(a, acc, cm0, cn0, wm, wn, lane);
+        if constexpr (EPI == EPI_QKROPE) epilogue256_qkrope(a, acc, cm0, cn0, wm, wn, wave, lane, (float*)(lds + T::LDS_BYTES), full);
+        else epilogue_tile<EPI, 8>(a, acc, cm0 + wm * 128, cn0 + wn * 64, lane, full);
         stores_in_flight = full;
     }
 }
@@ -425,54 +475,6 @@ static int launch256p(GemmArgs a, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------
 // Persistent 256x128 engine (gemm_tile256x128.h) for the N = 2048 projections.
-template <int EPI>
-__device__ __forceinline__ void epilogue256x128(const GemmArgs& a, const f32x4_t (&acc)[4][4], int m0, int n0, int wm, int wn, int lane) {
-    const int tok = lane & 15, fq = (lane >> 4) * 4;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + tok;
-        if (m >= a.M) continue;
-        if constexpr (EPI == EPI_SWIGLU) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int n = (n0 + wn * 64) / 2 + p * 16 + fq;
-                if (n >= a.N / 2) continue;
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float gte = round_bf16(acc[2 * p][mt][r]);
-                    const float up = round_bf16(acc[2 * p + 1][mt][r]);
-                    o[r] = round_bf16(silu_f32(gte)) * up;
-                }
-                u32x2_t v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-                *(u32x2_t*)(a.C + (size_t)m * a.ldc_bytes + (size_t)n * 2) = v;
-            }
-        } else {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int n = n0 + wn * 64 + nt * 16 + fq;
-                if (n >= a.N) continue;
-                if constexpr (EPI == EPI_F32) {
-                    *(f32x4_t*)(a.C + (size_t)m * a.ldc_bytes + (size_t)n * 4) = acc[nt][mt];
-                } else {
-                    float o[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = acc[nt][mt][r];
-                    if constexpr (EPI == EPI_RESIDUAL) {
-                        const u32x2_t rv = *(const u32x2_t*)(a.R + (size_t)m * a.ldr_bytes + (size_t)n * 2);
-                        o[0] = round_bf16(o[0]) + bf16_bits_to_f32(rv[0] & 0xffff);
-                        o[1] = round_bf16(o[1]) + bf16_bits_to_f32(rv[0] >> 16);
-                        o[2] = round_bf16(o[2]) + bf16_bits_to_f32(rv[1] & 0xffff);
-                        o[3] = round_bf16(o[3]) + bf16_bits_to_f32(rv[1] >> 16);
-                    }
-                    u32x2_t v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-                    *(u32x2_t*)(a.C + (size_t)m * a.ldc_bytes + (size_t)n * 2) = v;
-                }
-            }
-        }
-    }
-}
-
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256x128p_bf16_kernel(GemmArgs a) {
     namespace T = tile256x128;
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x128p_bf16_kernel(GemmArgs a) {
             cur = nxt;
         }
         const bool full = cm0 + T::BM <= a.M && cn0 + T::BN <= a.N;
-        epilogue256x128<EPI>(a, acc, cm0, cn0, wm, wn, lane);
+        epilogue_tile<EPI, 4>(a, acc, cm0 + wm * 64, cn0 + wn * 64, lane, full);
         stores_in_flight = full;
     }
 }
