@@ -170,7 +170,7 @@ def main():
                 tpath = os.path.join(ROOT, "profiles", "traffic.json")
                 if os.path.exists(tpath):
                     traffic = json.load(open(tpath)).get("gate_up_hbm_bytes_per_launch")
-                line["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel<SWIGLU> (gate|up projection + SiLU*up)",
+                line["roofline"] = {"bound": "mfma", "kernel": "gemm256p_bf16_kernel<SWIGLU> (gate|up projection + SiLU*up, persistent 256x256 engine)",
                                     "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                     "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
                                     "avg_launch_ms": dom["avg_ms"], "flops_per_launch": dom["flops_per_launch"],
