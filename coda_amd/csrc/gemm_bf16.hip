@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
 // 256x256 engine (gemm_tile256.h): same epilogues, no row gather.
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs a) {
+    using T = tile256::Tile<4>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -177,9 +178,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs a) {
     const int gsz = min(a.tiles_m - gm0, GROUP_M);
     const int tm = gm0 + (id % per_group) % gsz;
     const int tn = (id % per_group) / gsz;
-    const int m0 = tm * tile256::BM, n0 = tn * tile256::BN;
+    const int m0 = tm * T::BM, n0 = tn * T::BN;
 
-    tile256::Src src;
+    T::Src src;
     src.xbase = a.X;
     src.wbase = a.W;
     const int ch = tile256::dma_chunk(lane) * 16;
@@ -198,23 +199,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    tile256::mainloop(src, a.K, lds, wave, lane, acc);
+    T::mainloop(src, a.K, lds, wave, lane, acc);
 
-    epilogue_tile<EPI, 8>(a, acc, m0 + wm * 128, n0 + wn * 64, lane, m0 + tile256::BM <= a.M && n0 + tile256::BN <= a.N);
+    epilogue_tile<EPI, 8>(a, acc, m0 + wm * 128, n0 + wn * 64, lane, m0 + T::BM <= a.M && n0 + T::BN <= a.N);
 }
 
 template <int EPI>
 static int launch256(GemmArgs a, hipStream_t s) {
+    using T = tile256::Tile<4>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                tile256::LDS_BYTES) != hipSuccess)
+                                T::LDS_BYTES) != hipSuccess)
             return CODA_ERR_LAUNCH;
         attr_done = true;
     }
-    a.tiles_m = (a.M + tile256::BM - 1) / tile256::BM;
-    a.tiles_n = (a.N + tile256::BN - 1) / tile256::BN;
-    hipLaunchKernelGGL(gemm256_bf16_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(512), tile256::LDS_BYTES, s, a);
+    a.tiles_m = (a.M + T::BM - 1) / T::BM;
+    a.tiles_n = (a.N + T::BN - 1) / T::BN;
+    hipLaunchKernelGGL(gemm256_bf16_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(512), T::LDS_BYTES, s, a);
     CODA_CHECK_LAUNCH("gemm256_bf16");
     return CODA_OK;
 }
@@ -341,9 +343,18 @@ __device__ __forceinline__ void epilogue256_qkrope(const GemmArgs& a, f32x4_t (&
 // LDS-DMA stream and the fragment prefetch run CONTINUOUSLY across output-tile boundaries, so the
 // first K tiles of the next output tile are already landing while the current tile's epilogue
 // stores - no per-tile prologue bubble (worth ~8 % at K = 2048).
-template <int EPI>
+template <int MTH>
+struct PersistentLds {
+    using T = tile256::Tile<MTH>;
+    static constexpr int WST = MTH == 3 ? 3 : 2;                 // W ring depth
+    static constexpr int XR = 2 * T::X_BYTES;                    // W ring base (after the 2-stage X ring)
+    static constexpr int BYTES = XR + WST * T::W_BYTES;          // 128 KiB (256-token tile) / 144 KiB (192-token tile)
+};
+
+template <int EPI, int MTH>
 __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
-    namespace T = tile256;
+    using T = tile256::Tile<MTH>;
+    static_assert(EPI != EPI_QKROPE || MTH == 4, "the fused q/k epilogue is written for 256-token tiles");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -362,112 +373,148 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
         m0 = (gm0 + (L % per_group) % gsz) * T::BM;
         n0 = ((L % per_group) / gsz) * T::BN;
     };
-    T::Src src;
-    src.xbase = a.X;
-    src.wbase = a.W;
-    const int ch = T::dma_chunk(lane) * 16;
-    auto make_src = [&](int m0, int n0) {
+    // LDS: X ring of 2 stages, then W ring of WST stages.  The 192-token tile leaves room for a third W
+    // stage: the weight panel is the operand that comes cold from HBM (every layer has its own), so its
+    // DMA runs one K tile further ahead than the activations' (which the previous kernel left in cache).
+    constexpr int WST = PersistentLds<MTH>::WST;
+    constexpr int XR = PersistentLds<MTH>::XR;
+    const int ch = tile256::dma_chunk(lane) * 16;
+    unsigned xoff[T::X_DMA], woff[4];           // per-lane byte offsets of the DMA instructions of each operand
+    auto set_x = [&](int m0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = T::dma_row(i, wave, lane);
-            src.xoff[i] = (unsigned)((size_t)min(m0 + r, a.M - 1) * a.ldx_bytes + ch);
-            src.woff[i] = (unsigned)((size_t)min(n0 + r, a.N - 1) * a.ldw_bytes + ch);
-        }
+        for (int i = 0; i < T::X_DMA; ++i)
+            xoff[i] = (unsigned)((size_t)min(m0 + tile256::dma_row(i, wave, lane), a.M - 1) * a.ldx_bytes + ch);
+    };
+    auto set_w = [&](int n0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            woff[i] = (unsigned)((size_t)min(n0 + tile256::dma_row(i, wave, lane), a.N - 1) * a.ldw_bytes + ch);
     };
 
     int Lc = slot;
     if (Lc >= ntiles) return;
     int cm0, cn0;
     coords(Lc, cm0, cn0);
-    make_src(cm0, cn0);
-    int dL = Lc, dk = 0;                     // DMA cursor: the next K tile to T::stage is (dL, dk)
-    auto dma_next = [&](char* dst) {
-        if (dL < ntiles) {
-            T::stage(src, (size_t)dk * T::BK * 2, dst, wave);
-            if (++dk == nk) {
-                dk = 0;
-                dL += G;
-                if (dL < ntiles) {
+    set_x(cm0);
+    set_w(cn0);
+    // two DMA cursors over the workgroup's stream of K tiles (output tile, K tile): the next one to stage
+    int xL = Lc, xk = 0, wL = Lc, wk = 0;
+    auto dma_x = [&](char* dst) {
+        if (xL < ntiles) {
+            const size_t kb = (size_t)xk * T::BK * 2;
+#pragma unroll
+            for (int i = 0; i < T::X_DMA; ++i) glds16(a.X + kb + xoff[i], dst + (i * 8 + wave) * 1024);
+            if (++xk == nk) {
+                xk = 0;
+                xL += G;
+                if (xL < ntiles) {
                     int m0, n0;
-                    coords(dL, m0, n0);
-                    make_src(m0, n0);
+                    coords(xL, m0, n0);
+                    set_x(m0);
                 }
             }
         }
     };
-    dma_next(lds);
-    dma_next(lds + T::STAGE_BYTES);
-    T::tile_sync();
+    auto dma_w = [&](char* dst) -> bool {
+        if (wL >= ntiles) return false;
+        const size_t kb = (size_t)wk * T::BK * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(a.W + kb + woff[i], dst + (i * 8 + wave) * 1024);
+        if (++wk == nk) {
+            wk = 0;
+            wL += G;
+            if (wL < ntiles) {
+                int m0, n0;
+                coords(wL, m0, n0);
+                set_w(n0);
+            }
+        }
+        return true;
+    };
+    dma_x(lds);
+    dma_x(lds + T::X_BYTES);
+#pragma unroll
+    for (int i = 0; i < WST; ++i) dma_w(lds + XR + i * T::W_BYTES);
+    tile256::tile_sync();
 
     const int r16 = lane & 15, kq = lane >> 4, sw = lane & 7;
     const int p0 = ((0 * 4 + kq) ^ sw) * 16, p1 = ((1 * 4 + kq) ^ sw) * 16;
-    const char* xs = lds + (wm * 128 + r16) * 128;
-    const char* ws = lds + T::OP_BYTES + (wn * 64 + r16) * 128;
-    T::Frags f;
-    T::load_w<0, 0>(f, ws, p0);
-    T::load_x<0, 0>(f, xs, p0);
+    const char* xs = lds + (wm * (T::BM / 2) + r16) * 128;
+    const char* ws = lds + XR + (wn * 64 + r16) * 128;
+    typename T::Frags f;
+    T::template load_w<0, 0>(f, ws, p0);
+    T::template load_x<0, 0>(f, xs, p0);
 
-    constexpr int EPI_VMEM = (EPI == EPI_SWIGLU) ? 16 : 32;   // stores one wave issues per full tile
-    int cur = 0;                              // byte offset of the LDS T::stage holding the current K tile
+    constexpr int EPI_VMEM = (EPI == EPI_SWIGLU ? 2 : 4) * T::MT;   // stores one wave issues per full tile
+    int xcur = 0, wcur = 0;                   // byte offsets of the ring stages holding the current K tile
     bool stores_in_flight = false;            // previous tile's epilogue was the unconditional (full-tile) one
+    bool w_young = false;                     // WST == 3: a W DMA younger than what the next sync needs is in flight
     for (; Lc < ntiles; Lc += G) {
         coords(Lc, cm0, cn0);
-        f32x4_t acc[4][8];
+        f32x4_t acc[4][T::MT];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < T::MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         for (int t = 0; t < nk; ++t) {
-            const int nxt = T::STAGE_BYTES - cur;
-            const char* xc = xs + cur;
-            const char* wc = ws + cur;
-            T::phase_begin(); T::load_w<1, 1>(f, wc, p0); T::quad<0, 0, 0, 0>(f, acc);
-            T::phase_begin(); T::load_x<1, 1>(f, xc, p0); T::quad<1, 0, 1, 0>(f, acc);
-            T::phase_begin(); T::load_x<0, 0>(f, xc, p1); T::quad<1, 1, 1, 1>(f, acc);
-            T::phase_begin(); T::load_w<1, 1>(f, wc, p1); T::quad<0, 1, 0, 1>(f, acc);
-            T::phase_begin(); T::load_w<0, 0>(f, wc, p1); T::quad<1, 0, 1, 0>(f, acc);
-            T::phase_begin(); T::load_x<1, 1>(f, xc, p1); T::quad<0, 0, 0, 0>(f, acc);
-            // every wave has retired its reads of this T::stage; the next K tile of the stream (DMA issued one
-            // K tile ago, i.e. older than any epilogue store still in flight) has landed
-            if (stores_in_flight && t == 0) {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(EPI_VMEM) : "memory");
+            const int xnxt = T::X_BYTES - xcur;
+            const int wnxt = wcur == (WST - 1) * T::W_BYTES ? 0 : wcur + T::W_BYTES;
+            const char* xc = xs + xcur;
+            const char* wc = ws + wcur;
+            tile256::phase_begin(); T::template load_w<1, 1>(f, wc, p0); T::template quad<0, 0, 0, 0>(f, acc);
+            tile256::phase_begin(); T::template load_x<1, 1>(f, xc, p0); T::template quad<1, 0, 1, 0>(f, acc);
+            tile256::phase_begin(); T::template load_x<0, 0>(f, xc, p1); T::template quad<1, 1, 1, 1>(f, acc);
+            tile256::phase_begin(); T::template load_w<1, 1>(f, wc, p1); T::template quad<0, 1, 0, 1>(f, acc);
+            tile256::phase_begin(); T::template load_w<0, 0>(f, wc, p1); T::template quad<1, 0, 1, 0>(f, acc);
+            tile256::phase_begin(); T::template load_x<1, 1>(f, xc, p1); T::template quad<0, 0, 0, 0>(f, acc);
+            // Every wave has retired its reads of these stages, and the next K tile of the stream must have
+            // landed.  vmcnt retires in order, so what may stay in flight is exactly what was issued AFTER
+            // the next tile's DMA: the W tile one further ahead (4 instructions, 3-stage ring only) and the
+            // previous output tile's epilogue stores.
+            {
+                const bool st = stores_in_flight && t == 0;
+                if (WST == 3 && w_young && st) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(EPI_VMEM + 4) : "memory");
+                else if (WST == 3 && w_young) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                else if (st) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(EPI_VMEM) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-            } else {
-                T::tile_sync();
             }
             __builtin_amdgcn_sched_barrier(0);
-            dma_next(lds + cur);
-            T::load_x<0, 0>(f, xs + nxt, p0);       // first fragments of the next K tile (stale bytes after the last one: unused)
-            T::quad<0, 1, 0, 1>(f, acc);
-            T::phase_begin();
-            T::load_w<0, 0>(f, ws + nxt, p0);
-            T::quad<1, 1, 1, 1>(f, acc);
-            cur = nxt;
+            dma_x(lds + xcur);
+            w_young = dma_w(lds + XR + wcur);
+            T::template load_x<0, 0>(f, xs + xnxt, p0);      // first fragments of the next K tile (stale bytes after the last one: unused)
+            T::template quad<0, 1, 0, 1>(f, acc);
+            tile256::phase_begin();
+            T::template load_w<0, 0>(f, ws + wnxt, p0);
+            T::template quad<1, 1, 1, 1>(f, acc);
+            xcur = xnxt;
+            wcur = wnxt;
         }
         const bool full = cm0 + T::BM <= a.M && cn0 + T::BN <= a.N;
-        if constexpr (EPI == EPI_QKROPE) epilogue256_qkrope(a, acc, cm0, cn0, wm, wn, wave, lane, (float*)(lds + T::LDS_BYTES), full);
-        else epilogue_tile<EPI, 8>(a, acc, cm0 + wm * 128, cn0 + wn * 64, lane, full);
+        if constexpr (EPI == EPI_QKROPE) epilogue256_qkrope(a, acc, cm0, cn0, wm, wn, wave, lane, (float*)(lds + PersistentLds<MTH>::BYTES), full);
+        else epilogue_tile<EPI, T::MT>(a, acc, cm0 + wm * (T::BM / 2), cn0 + wn * 64, lane, full);
         stores_in_flight = full;
     }
 }
 
-template <int EPI>
+template <int EPI, int MTH = 4>
 static int launch256p(GemmArgs a, hipStream_t s) {
+    using T = tile256::Tile<MTH>;
     static bool attr_done = false;
     static int n_cu = 256;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)gemm256p_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                tile256::LDS_BYTES + 4096) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)gemm256p_bf16_kernel<EPI, MTH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                PersistentLds<MTH>::BYTES + 4096) != hipSuccess)
             return CODA_ERR_LAUNCH;
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             n_cu = cus;
         attr_done = true;
     }
-    a.tiles_m = (a.M + tile256::BM - 1) / tile256::BM;
-    a.tiles_n = (a.N + tile256::BN - 1) / tile256::BN;
+    a.tiles_m = (a.M + T::BM - 1) / T::BM;
+    a.tiles_n = (a.N + T::BN - 1) / T::BN;
     const int grid = a.tiles_m * a.tiles_n < n_cu ? a.tiles_m * a.tiles_n : n_cu;
-    hipLaunchKernelGGL(gemm256p_bf16_kernel<EPI>, dim3(grid), dim3(512), tile256::LDS_BYTES + (EPI == EPI_QKROPE ? 4096 : 0), s, a);
+    hipLaunchKernelGGL((gemm256p_bf16_kernel<EPI, MTH>), dim3(grid), dim3(512), PersistentLds<MTH>::BYTES + (EPI == EPI_QKROPE ? 4096 : 0), s, a);
     CODA_CHECK_LAUNCH("gemm256p_bf16");
     return CODA_OK;
 }
@@ -614,14 +661,19 @@ static int launch256x128p(GemmArgs a, hipStream_t s) {
     return CODA_OK;
 }
 
-static int g_gemm_variant = 0;   // 0 auto, 1 force 128x128, 2 force 256x256 (one tile per workgroup), 3 force persistent 256x256, 4 force persistent 256x128
+template <int EPI>
+static int launch192x256p(GemmArgs a, hipStream_t s) { return launch256p<EPI, 3>(a, s); }
+
+// 0 auto, 1 force 128x128, 2 force 256x256 (one tile per workgroup), 3 force persistent 256x256,
+// 4 force persistent 256x128, 5 force persistent 192x256
+static int g_gemm_variant = 0;
 extern "C" int coda_gemm_select(int variant) {
-    if (variant < 0 || variant > 4) return CODA_ERR_ARG;
+    if (variant < 0 || variant > 5) return CODA_ERR_ARG;
     g_gemm_variant = variant;
     return CODA_OK;
 }
 
-// -> 0: 128x128 engine, 2: 256x256 one tile per workgroup, 3: persistent 256x256, 4: persistent 256x128
+// -> 0: 128x128 engine, 2: 256x256 one tile per workgroup, 3: persistent 256x256, 4: persistent 256x128, 5: persistent 192x256
 static int pick_engine(const GemmArgs& a) {
     if (a.x_rows) return 0;
     // per-lane 32-bit DMA offsets: the operand panels of one launch must span < 4 GiB
@@ -633,7 +685,9 @@ static int pick_engine(const GemmArgs& a) {
     auto fill = [](long tiles) { const long rounds = (tiles + 255) / 256; return (double)tiles / (double)(rounds * 256); };
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     const long t128 = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
+    const long t192 = (long)((a.M + 191) / 192) * ((a.N + 255) / 256);
     if (a.N >= 256 && t256 >= 200 && fill(t256) >= 0.85) return 3;
+    if (a.N >= 256 && t192 >= 200 && fill(t192) >= 0.85) return 5;    // e.g. 12288 x 2048: 512 tiles = 2 full rounds
     if (t128 >= 200 && fill(t128) >= 0.85) return 4;
     return 0;
 }
@@ -679,6 +733,7 @@ extern "C" int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, c
         case EPI_F32: return fn<EPI_F32>(a, s);                \
         default: return CODA_ERR_ARG;                          \
     }
+    if (engine == 5) { CODA_DISPATCH(launch192x256p) }
     if (engine == 4) { CODA_DISPATCH(launch256x128p) }
     if (engine == 3) { CODA_DISPATCH(launch256p) }
     if (engine == 2) { CODA_DISPATCH(launch256) }

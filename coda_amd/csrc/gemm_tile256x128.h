@@ -34,7 +34,7 @@ __device__ __forceinline__ void stage(const Src& s, size_t kbyte, char* lds_stag
     for (int i = 0; i < 2; ++i) glds16(s.wbase + kbyte + s.woff[i], lds_stage + X_BYTES + (i * 8 + wave) * 1024);
 }
 
-using tile256::Frags;
+using Frags = tile256::Tile<4>::Frags;
 using tile256::phase_begin;
 using tile256::tile_sync;
 

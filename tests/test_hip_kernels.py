@@ -66,7 +66,7 @@ def test_gemm_exact_integer(M, N, K):
     assert torch.equal(out, ref.to(BF))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("M,N,K,epi", [(512, 512, 64, "f32"), (768, 256, 192, "plain"), (300, 520, 128, "f32"),
                                        (1024, 768, 2048, "res"), (515, 512, 320, "res"), (8192, 5120, 128, "plain"),
                                        (8192 + 40, 4096 + 128, 64, "res")])
@@ -90,7 +90,7 @@ def test_gemm_engines_exact_integer(variant, M, N, K, epi):
         lib.coda_gemm_select(0)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 def test_gemm_engines_swiglu(variant):
     from coda_amd.engine import interleave_gate_up
     lib = _lib.load()
