@@ -66,10 +66,10 @@ if os.path.exists(fp) and os.path.exists(wp):
             traffic[k] = rb + wb
             f.write(f"{k},{n},{fk:.1f},{wk:.1f},{rb:.0f},{wb:.0f},{rb+wb:.0f}\n")
     # the gate|up projection (SwiGLU epilogue, template argument 2) on whichever tile engine ran it
-    gate_up = [v for k, v in traffic.items() if k.startswith("gemm") and "_kernel<2>" in k]
+    gate_up = [v for k, v in traffic.items() if k.startswith("gemm") and "_kernel<2" in k]
     out = {"source": f"profiles/{tag}_hbm_traffic.csv", "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB->bytes, per launch"}
     if gate_up:
         out["gate_up_hbm_bytes_per_launch"] = max(gate_up)
-        out["gate_up_kernel"] = max((k for k in traffic if k.startswith("gemm") and "_kernel<2>" in k), key=lambda k: traffic[k]).split("|")[0]
+        out["gate_up_kernel"] = max((k for k in traffic if k.startswith("gemm") and "_kernel<2" in k), key=lambda k: traffic[k]).split("|")[0]
     json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print("traffic:", {k: f"{v/1e6:.1f} MB" for k, v in list(traffic.items())[:12]})
