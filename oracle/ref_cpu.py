@@ -402,6 +402,32 @@ def diffusion_generate(sd, dims: Dims, input_ids: torch.Tensor, *, max_new_token
                            max_steps=max_steps)
 
 
+# --------------------------------------------------------------------------- lm-eval adapter (id level)
+def generate_batch_ids(generate_fn, prompts, *, pad_id: int, eos_id: int, max_prompt_len: int) -> List[List[int]]:
+    """Id-level restatement of ``DiffLLM._generate_batch`` (evaluation/lm_eval/lm_eval/models/diffllm.py:265-295).
+
+    ``generate_fn(prompt_ids[B, P], attn_mask[B, P]) -> sequences[B, L]`` stands for the
+    ``model.diffusion_generate(...)`` call of :275-287.  The tokenizer steps become: left padding with
+    ``pad_id`` (:267), the ``[:, -max_prompt_len:]`` slice (:268), the mask ``ids != pad`` (:269), and
+    ``decode(g[len(p):]).split(eos_token)[0]`` (:291) = the ids before the first ``eos_id``.
+    Parity of these six lines is by restatement only (the module cannot be imported here: its package
+    needs ``sacrebleu``); the ``diffusion_generate`` call on left-padded prompts is pinned by the
+    ``lmeval_*`` golden vectors."""
+    width = max(len(p) for p in prompts)
+    ids = torch.full((len(prompts), width), pad_id, dtype=torch.long)
+    for r, p in enumerate(prompts):
+        if len(p):
+            ids[r, width - len(p):] = torch.tensor(list(p), dtype=torch.long)
+    ids = ids[:, -max_prompt_len:]
+    attn = ids.ne(pad_id)
+    seqs = generate_fn(ids, attn)
+    out = []
+    for p, g in zip(ids, seqs):
+        tail = g[len(p):].tolist()
+        out.append(tail[:tail.index(eos_id)] if eos_id in tail else tail)
+    return out
+
+
 # --------------------------------------------------------------------------- online forms (SURVEY A.4)
 def online_confidence(logits: torch.Tensor, alg: str, temperature: float = 0.0, q: Optional[torch.Tensor] = None,
                       tile: int = 128):

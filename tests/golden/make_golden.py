@@ -199,6 +199,53 @@ def main():
     ka = top_p_logits(torch.tensor([[2.0, 1.0, 0.5, 0.0, -1.0]]), 0.9)
     out["st_known_topp"] = ka.numpy()
 
+    # ---- G7: the lm-eval adapter's call shape (evaluation/lm_eval/lm_eval/models/diffllm.py:265-295): left-padded
+    #          unequal prompts cut to the last max_prompt_len columns, attention_mask passed (and ignored, F3),
+    #          return_dict_in_generate=True / output_history=False, the eval scripts' sampling settings
+    for name, kw, dtype, wseed in (("lmeval_tiny_f32", TINY, torch.float32, 31), ("lmeval_small_f32", SMALL, torch.float32, 32),
+                                   ("lmeval_small_bf16", SMALL, torch.bfloat16, 32)):
+        d = ref_cpu.Dims(**kw)
+        sd32 = ref_cpu.make_state_dict(d, wseed, torch.float32, lm_head_gain=8.0, norm_jitter=0.1)
+        sd = {k: v.to(dtype) for k, v in sd32.items()}
+        m = ref_model(d, sd32, dtype)
+        g = torch.Generator().manual_seed(77)
+        lens = [9, 4, 12, 1]
+        plist = [torch.randint(0, min(d.pad_id, d.mask_id), (n,), generator=g).tolist() for n in lens]
+        width, max_prompt_len = max(lens), 10
+        ids = torch.full((len(lens), width), d.pad_id, dtype=torch.long)
+        for r, pr in enumerate(plist):
+            ids[r, width - len(pr):] = torch.tensor(pr)
+        ids = ids[:, -max_prompt_len:]
+        attn = ids.ne(d.pad_id)
+        for ci, c in enumerate((dict(steps=16, temperature=0.1, top_p=0.9, alg="entropy", alg_temp=0.0, seed=41),
+                                dict(steps=8, temperature=0.0, top_p=0.9, alg="entropy", alg_temp=0.0, seed=None),
+                                dict(steps=16, temperature=0.1, top_p=0.9, top_k=40, alg="maskgit_plus", alg_temp=0.1, seed=43))):
+            c = dict(c)
+            seed = c.pop("seed")
+            G = 16
+            outs = []
+            for hist in (False, True):
+                if seed is not None:
+                    torch.manual_seed(seed)
+                gc = DLMGenerationConfig(mask_token_id=d.mask_id, pad_token_id=d.pad_id, eos_token_id=d.pad_id + 1,
+                                         return_dict_in_generate=True, output_history=hist, max_new_tokens=G, **c)
+                with torch.no_grad():
+                    outs.append(m.diffusion_generate(ids, generation_config=gc, attention_mask=attn))
+            assert outs[0].history is None and torch.equal(outs[0].sequences, outs[1].sequences)
+            if seed is not None:
+                torch.manual_seed(seed)
+            tr = ref_cpu.diffusion_generate(sd, d, ids, max_new_tokens=G, **c)
+            same = torch.equal(tr.sequences, outs[0].sequences) and torch.equal(torch.stack(tr.history), torch.stack(list(outs[1].history)))
+            print(f"  {name}[{ci}] {c} oracle==reference: {same}")
+            assert same, "oracle diverges from the reference on the lm-eval call shape"
+            key = f"{name}_{ci}"
+            out[key + "_seq"] = outs[0].sequences.numpy()
+            out[key + "_hist"] = torch.stack(list(outs[1].history)).numpy().astype(np.int32)
+            out[key + "_meta"] = np.array(repr(dict(dims=kw, dtype=str(dtype), weight_seed=wseed, gain=8.0, norm_jitter=0.1,
+                                                    G=G, seed=seed, max_prompt_len=max_prompt_len, **c)))
+        out[name + "_prompts"] = np.array(repr(plist))
+        out[name + "_ids"] = ids.numpy()
+
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     sz = os.path.getsize(os.path.join(HERE, "reference_vectors.npz"))
     print(f"wrote reference_vectors.npz ({sz/1e6:.2f} MB, {len(out)} arrays)")

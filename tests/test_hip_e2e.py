@@ -235,3 +235,40 @@ def test_device_rng_is_reproducible(small):
     c = m.diffusion_generate(ids, **kw)
     assert torch.equal(a, b) and not torch.equal(a, c)
     assert (a != d.mask_id).all()
+
+
+@pytest.mark.parametrize("temperature", [0.0, 0.1])
+def test_lm_eval_adapter_left_padded(small, temperature):
+    """the lm-eval adapter's call shape (diffllm.py:265-295) on the HIP path - unequal prompts left-padded
+    and cut to max_prompt_len, attention_mask passed, top_p = 0.9 with T = 0 (deterministic) and the eval scripts'
+    T = 0.1 (noise replayed from the oracle)."""
+    from coda_amd.lm_eval_adapter import DiffLLMAdapter
+    from parity import teacher_forced
+    d, sd, m = small
+    g = torch.Generator().manual_seed(77)
+    prompts = [torch.randint(0, d.pad_id, (n,), generator=g).tolist() for n in (9, 4, 12, 1)]
+    a = DiffLLMAdapter(m, batch_size=4, max_prompt_len=10, max_new_tokens=16, diffusion_steps=16, temperature=temperature, top_p=0.9)
+    ids, attn = a.prepare_batch(prompts)
+    assert ids.shape == (4, 10) and (ids[3, :9] == d.pad_id).all() and attn.dtype == torch.bool
+    kw = dict(max_new_tokens=16, steps=16, alg="entropy", temperature=temperature, top_p=0.9, alg_temp=0.0)
+    extra, log = {}, None
+    if temperature > 0:
+        torch.manual_seed(321)
+        noise = ref_cpu.TorchNoise()
+        ref_cpu.diffusion_generate(sd, d, ids.cpu(), noise=noise, **kw)
+        extra, log = dict(noise_source=Replay(noise.log, d.vocab)), noise.log
+    gk = a.generation_kwargs()
+    gk.update(output_history=True)
+    trace = []
+    out = m.diffusion_generate(ids, attention_mask=attn, debug_trace=trace, **extra, **gk)
+    assert (out.sequences[:, :10] == ids).all() and (out.sequences != d.mask_id).all()
+    stats, _ = teacher_forced(sd, d, ids.cpu(), [h.cpu() for h in out.history], trace, noise_log=log, **kw)
+    print(f"lm-eval shape T={temperature}: {stats['exact_steps']}/16 steps identical, {stats['band_tok']} tok-band, "
+          f"max conf err {stats['max_conf_err']:.4g}, {len(stats['violations'])} violations")
+    assert not stats["violations"], stats["violations"][:5]
+    if temperature == 0:
+        resp = a.generate_batch_ids(prompts)
+        eos = d.pad_id + 1
+        for r, row in zip(resp, out.sequences.cpu()):
+            tail = row[10:].tolist()
+            assert r == (tail[:tail.index(eos)] if eos in tail else tail)

@@ -144,3 +144,38 @@ def test_online_forms_match_sample_tokens():
     c, x0 = ref_cpu.sample_tokens(logits, 0.7, noise=N())
     oc, ox0 = ref_cpu.online_confidence(logits, "maskgit_plus", 0.7, q)
     assert torch.equal(x0, ox0) and (c.double() - oc).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("prefix", ["lmeval_tiny_f32", "lmeval_small_f32", "lmeval_small_bf16"])
+def test_lm_eval_call_shape(golden, prefix):
+    """Left-padded, truncated prompts + attention_mask + the eval scripts' sampling settings
+    (diffllm.py:265-295), as run through the reference model: tokens and per-step histories exact."""
+    ids = torch.from_numpy(golden[prefix + "_ids"])
+    plist = ast.literal_eval(str(golden[prefix + "_prompts"]))
+    keys = _e2e_keys(golden, prefix)
+    assert len(keys) == 3
+    for key in keys:
+        meta = _meta(golden, key + "_meta")
+        d = ref_cpu.Dims(**meta["dims"])
+        dt = DT[meta["dtype"]]
+        sd = ref_cpu.make_state_dict(d, meta["weight_seed"], torch.float32, meta["gain"], meta["norm_jitter"])
+        sd = {k: v.to(dt) for k, v in sd.items()}
+        kw = {k: meta[k] for k in ("steps", "temperature", "top_p", "alg", "alg_temp") if k in meta}
+        if "top_k" in meta:
+            kw["top_k"] = meta["top_k"]
+
+        def gen(pids, attn):
+            assert torch.equal(pids, ids) and torch.equal(attn, ids.ne(d.pad_id))
+            if meta["seed"] is not None:
+                torch.manual_seed(meta["seed"])
+            tr = ref_cpu.diffusion_generate(sd, d, pids, max_new_tokens=meta["G"], **kw)
+            assert torch.equal(torch.stack(tr.history), torch.from_numpy(golden[key + "_hist"]).long())
+            return tr.sequences
+
+        # the id-level adapter restatement: padding/truncation reproduce the stored ids, the continuation is
+        # the reference's sequence after the padded width, cut before the first eos
+        resp = ref_cpu.generate_batch_ids(gen, plist, pad_id=d.pad_id, eos_id=d.pad_id + 1, max_prompt_len=meta["max_prompt_len"])
+        ref_seq = torch.from_numpy(golden[key + "_seq"])
+        for r, row in zip(resp, ref_seq):
+            tail = row[ids.shape[1]:].tolist()
+            assert r == (tail[:tail.index(d.pad_id + 1)] if d.pad_id + 1 in tail else tail)

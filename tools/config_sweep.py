@@ -27,6 +27,9 @@ CONFIGS = [
     ("C3/GPU window", 64, 512, 256, 128, 32, dict(alg="entropy"), 16),
     ("C4 long", 8, 1024, 1024, 512, 64, dict(alg="maskgit_plus", temperature=0.7, top_p=0.9), 32),
     ("C5 few-step", 128, 128, 512, 32, None, dict(alg="topk_margin", alg_temp=0.1), 4),
+    # the lm-eval scripts' workload (eval_mbpp_humaneval.sh: batch 32, 768 new tokens, 768 steps, T=0.1,
+    # top_p=0.9, entropy); the first steps (every generated position still masked) are the expensive ones
+    ("E1 lm-eval", 32, 128, 768, 768, None, dict(alg="entropy", temperature=0.1, top_p=0.9, alg_temp=0.0), 8),
 ]
 only = sys.argv[1:] 
 for name, B, P, G, steps, bl, kw, run in CONFIGS:
