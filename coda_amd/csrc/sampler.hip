@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void select_unmask_kernel(long long* __restric
                                                             const long long* __restrict__ x0, const int* __restrict__ count,
                                                             int B, int L, int lo, int hi, long long mask_id, float ratio,
                                                             int take_all, float alg_temp, const float* __restrict__ noise,
-                                                            int* __restrict__ k_out) {
+                                                            int* __restrict__ k_out, int k_fixed, float threshold,
+                                                            int* __restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nw = hi - lo;
     float* key = (float*)smem;                 // [nw]
@@ -77,9 +78,12 @@ __global__ __launch_bounds__(256) void select_unmask_kernel(long long* __restric
     const int b = blockIdx.x;
 
     // k exactly as the reference: fp32 (sum / B) * (1 - s/t), truncated toward zero
-    const float n_mask = __fdiv_rn((float)count[0], (float)B);
-    const int k = take_all ? (int)n_mask : (int)__fmul_rn(n_mask, ratio);
+    const float n_mask = k_fixed >= 0 ? 0.f : __fdiv_rn((float)count[0], (float)B);
+    // k_fixed >= 0 (confidence_threshold alg): the host supplies the count; of the k best, the best is always
+    // revealed and the others only when their confidence reaches `threshold`; info = {revealed, held back}
+    const int k = k_fixed >= 0 ? k_fixed : (take_all ? (int)n_mask : (int)__fmul_rn(n_mask, ratio));
     if (b == 0 && tid == 0 && k_out) k_out[0] = k;
+    if (b == 0 && tid == 0 && info) info[0] = info[1] = 0;
     if (k <= 0) return;
 
     // ordered compaction of this row's masked window positions
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(256) void select_unmask_kernel(long long* __restric
     }
     const int n = n_s;
     if (n == 0) return;
+    int revealed = 0;
 
     if (alg_temp > 0.f) {
         // key = softmax(conf / alg_temp) / Exp(1) noise  (== multinomial without replacement)
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256) void select_unmask_kernel(long long* __restric
 
     for (int i = tid; i < n; i += 256) {
         bool take = true;
-        if (k < n) {
+        if (k < n || k_fixed >= 0) {
             const float ki = key[i];
             int rank = 0;
             for (int j = 0; j < n; ++j) {
@@ -139,10 +144,23 @@ __global__ __launch_bounds__(256) void select_unmask_kernel(long long* __restric
                 rank += (kj > ki) || (kj == ki && j < i);
             }
             take = rank < k;
+            if (k_fixed >= 0) take = take && (rank == 0 || !(ki < threshold));
         }
         if (take) {
             const size_t at = (size_t)b * L + cpos[i];
             x[at] = x0[at];
+            ++revealed;
+        }
+    }
+    if (info) {
+        __syncthreads();
+        revealed = (int)wave_sum((float)revealed);      // <= 16384 candidates: exact in fp32
+        if (lane == 0) wave_tot[wave] = revealed;
+        __syncthreads();
+        if (tid == 0) {
+            const int tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+            info[0] = tot;
+            info[1] = min(k, n) - tot;
         }
     }
 }
@@ -162,8 +180,27 @@ extern "C" int coda_select_unmask(long long* x, const float* conf, const long lo
         attr_done = true;
     }
     hipLaunchKernelGGL(select_unmask_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, x, conf, x0, count, B, L, win_lo,
-                       win_hi, mask_id, ratio, take_all, alg_temp, noise, k_out);
+                       win_hi, mask_id, ratio, take_all, alg_temp, noise, k_out, -1, 0.f, (int*)nullptr);
     CODA_CHECK_LAUNCH("select_unmask");
+    return CODA_OK;
+}
+
+// serving/dream/model/generation_utils.py:442-465 (`confidence_threshold`), one sequence
+extern "C" int coda_select_threshold(long long* x, const float* conf, const long long* x0, int L, int win_lo, int win_hi,
+                                     long long mask_id, int k, float threshold, int* info, void* stream) {
+    if (L <= 0 || win_lo < 0 || win_hi > L || win_lo >= win_hi || k < 0) return CODA_ERR_SHAPE;
+    if (win_hi - win_lo > 16384) return CODA_ERR_SHAPE;
+    if (!x || !conf || !x0 || !info) return CODA_ERR_ARG;
+    const size_t lds = (size_t)(win_hi - win_lo) * 8;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)select_unmask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8) != hipSuccess)
+            return CODA_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(select_unmask_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, x, conf, x0, (const int*)nullptr, 1, L,
+                       win_lo, win_hi, mask_id, 0.f, 0, 0.f, (const float*)nullptr, (int*)nullptr, k, threshold, info);
+    CODA_CHECK_LAUNCH("select_threshold");
     return CODA_OK;
 }
 

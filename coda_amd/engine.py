@@ -212,6 +212,18 @@ class HipEngine:
         _lib.call("coda_select_unmask", _ptr(x), _ptr(self.conf), _ptr(self.x0), _ptr(self.count), B, L, lo, hi, self._mask_id,
                   float(ratio), int(take_all), float(alg_temp), _ptr(noise), _ptr(self.k_out), self._stream())
 
+    def select_threshold(self, x: torch.Tensor, lo: int, hi: int, k: int, threshold: float):
+        """One sequence; returns (revealed, held_back) - the alg's one host read per step (the loop length depends on it)."""
+        B, L = x.shape
+        if B != 1:
+            raise CodaHipError("confidence_threshold works on one sequence")
+        if getattr(self, "_thr_info", None) is None:
+            self._thr_info = torch.zeros(2, dtype=torch.int32, device=x.device)
+        _lib.call("coda_select_threshold", _ptr(x), _ptr(self.conf), _ptr(self.x0), L, lo, hi, self._mask_id, int(k),
+                  float(threshold), _ptr(self._thr_info), self._stream())
+        revealed, held = self._thr_info.tolist()
+        return revealed, held
+
     def origin_transfer(self, x: torch.Tensor, max_rows: int, u: torch.Tensor, p_transfer: float):
         _lib.call("coda_origin_transfer", _ptr(x), _ptr(self.x0), _ptr(self.dst_pos), _ptr(self.count), max_rows, _ptr(u),
                   float(p_transfer), self._stream())

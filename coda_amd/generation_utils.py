@@ -175,6 +175,8 @@ class DLMGenerationMixin:
         logits_hook = kwargs.pop("generation_logits_hook_func", None)
         attention_mask = kwargs.pop("attention_mask", None)
         noise_source = kwargs.pop("noise_source", None)
+        # the serving sampler's extra keyword (serving/dream/model/generation_utils.py:357), used by alg="confidence_threshold"
+        self._threshold = kwargs.pop("threshold", 0.9)
         self._debug_trace = kwargs.pop("debug_trace", None)     # list: receives per-step device confidences (tests)
         had_max_length_kwarg = kwargs.get("max_length") is not None
         generation_config = self._prepare_generation_config(generation_config, **kwargs)
@@ -214,7 +216,7 @@ class DLMGenerationMixin:
         ``attention_mask`` is accepted and has no effect, as in the reference."""
         gc = generation_config
         alg, alg_temp, temperature = gc.alg, gc.alg_temp, float(gc.temperature or 0.0)
-        if alg not in ("origin", "maskgit_plus", "topk_margin", "entropy"):
+        if alg not in ("origin", "maskgit_plus", "topk_margin", "entropy", "confidence_threshold"):
             raise RuntimeError(f"Unknown alg: {alg}")
         eng = self.hip_engine()
         eng.set_mask_id(gc.mask_token_id)
@@ -233,13 +235,28 @@ class DLMGenerationMixin:
         top_k = gc.top_k
         materialise_all = logits_hook is not None or tokens_hook is not None
         fused = not materialise_all and top_p is None and top_k is None
-        alg_id = _lib.ALG_IDS.get(alg, 0)
+        alg_id = _lib.ALG_IDS.get(alg, 0)                # confidence_threshold scores like maskgit_plus: p[x0]
         a_temp = float(alg_temp) if alg_temp else 0.0
 
         if tokens_hook is not None:
             x = tokens_hook(None, x, None)
-        for i in range(gc.steps):
-            blk, j = divmod(i, steps_b)
+        steps = gc.steps
+        if alg == "confidence_threshold":
+            # serving/dream/model/generation_utils.py:416-422: one sequence, a fixed quota per step plus whatever
+            # earlier steps held back; the loop grows by one step whenever the last step still holds tokens back
+            if n_blocks != 1:
+                raise ValueError("confidence_threshold is defined on the reference (non-windowed) loop only")
+            n_masks = int((x == gc.mask_token_id).sum().item())
+            assert n_masks % steps == 0, "mask_index.sum() must be divisible by steps"
+            assert B == 1, "batch size must be 1"
+            quota, held_back = n_masks // steps, 0
+            threshold = float(self._threshold)
+            if round_conf:                                 # bf16 confidences compare against the bf16 threshold
+                threshold = float(torch.tensor(threshold, dtype=torch.bfloat16))
+        i = -1
+        while i + 1 < steps:
+            i += 1
+            blk, j = divmod(min(i, gc.steps - 1), steps_b)
             if n_blocks == 1:
                 # reference mode: every masked position of the row is a candidate (prompt included if it holds masks)
                 lo, hi = (0 if self._prompt_has_mask or tokens_hook is not None else P), L
@@ -278,6 +295,13 @@ class DLMGenerationMixin:
                                               dst=eng.dst_pos.clone(), lo=lo, hi=hi))
             if alg == "origin":
                 eng.origin_transfer(x, cap, u, p_transfer)
+            elif alg == "confidence_threshold":
+                current = quota + held_back
+                _, held = eng.select_threshold(x, lo, hi, current, threshold)
+                held_back = held
+                if held and i >= steps - 1:                # :459-463 - the last step may not leave tokens behind
+                    quota = 0
+                    steps += 1
             else:
                 sel_noise = noise.select_noise(i, B, L) if a_temp > 0 else None
                 eng.select_unmask(x, lo, hi, ratios[j], last, a_temp, sel_noise)

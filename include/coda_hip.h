@@ -131,6 +131,14 @@ int coda_select_unmask(long long* x, const float* conf, const long long* x0, con
                        int win_lo, int win_hi, long long mask_id, float ratio, int take_all, float alg_temp,
                        const float* noise, int* k_out, void* stream);
 
+/* `confidence_threshold` selection for ONE sequence.  Replaces the serving sampler's
+ * serving/dream/model/generation_utils.py:442-465: among the masked positions of x[0, win_lo:win_hi) take
+ * the k largest conf (ties: lowest index); the largest is always revealed, each of the others only if
+ * !(conf < threshold).  Writes x[p] = x0[p] for the revealed p; info[0] = number revealed,
+ * info[1] = number of the k held back (the reference's left_tokens_last_step increment). */
+int coda_select_threshold(long long* x, const float* conf, const long long* x0, int L, int win_lo, int win_hi,
+                          long long mask_id, int k, float threshold, int* info, void* stream);
+
 /* `origin` algorithm transfer (generation_utils.py:466-483): every candidate i < count[0] with
  * u[i] < p_transfer takes x[dst_pos[i]] = x0[dst_pos[i]].  u fp32 [count] uniform(0,1). */
 int coda_origin_transfer(long long* x, const long long* x0, const int* dst_pos, const int* count, int max_rows,

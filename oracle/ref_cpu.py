@@ -273,6 +273,7 @@ class SamplerArgs:
     top_k: Optional[int] = None
     block_length: Optional[int] = None
     output_history: bool = False
+    threshold: float = 0.9          # serving sampler only (alg == "confidence_threshold")
 
 
 @dataclass
@@ -317,12 +318,24 @@ def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: to
 
     if tokens_hook is not None:
         x = tokens_hook(None, x, None)
-    for i in range(args.steps):
+    steps = args.steps
+    if args.alg == "confidence_threshold":
+        # serving/dream/model/generation_utils.py:416-422
+        assert n_blocks == 1
+        mask_index = x == args.mask_id
+        assert mask_index.sum() % steps == 0, "mask_index.sum() must be divisible by steps"
+        assert x.shape[0] == 1, "batch size must be 1"
+        number_transfer_tokens = mask_index.sum().item() // steps
+        left_tokens_last_step = 0
+    i = -1
+    # teacher forcing walks exactly the given states (the threshold alg's own step count is data dependent)
+    while i + 1 < (steps if force_states is None else len(force_states)):
+        i += 1
         if max_steps is not None and i >= max_steps:      # bounded sample of the loop (bench.py cpu_baseline)
             break
         if force_states is not None:
             x = force_states[i].clone()
-        blk, j = divmod(i, steps_b)
+        blk, j = divmod(min(i, args.steps - 1), steps_b)
         lo, hi = P + blk * bl, P + (blk + 1) * bl
         mask_index = x == args.mask_id
         if n_blocks > 1:
@@ -349,6 +362,38 @@ def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: to
                     gap[pick] = dg["gap"]
                 tr.x0.append(x0.clone()); tr.gap.append(gap); tr.cand.append(mask_index.clone())
                 tr.key.append(None); tr.k.append(None); tr.absmax.append(None); tr.conf.append(None); tr.pmax.append(None)
+        elif args.alg == "confidence_threshold":
+            # serving/dream/model/generation_utils.py:442-465 (the serving sampler bound onto the CoDA model by
+            # serving/fast-api/app/core/service.py:99-120)
+            dg = {} if trace else None
+            conf, x0 = sample_tokens(rows, args.temperature, args.top_p, args.top_k, noise=noise, step=i, diag=dg)
+            cand = torch.full_like(x, args.mask_id)
+            cand[mask_index] = x0.clone()
+            full = torch.full(x.shape, -torch.inf, dtype=logits.dtype)
+            full[mask_index] = conf
+            current = number_transfer_tokens + left_tokens_last_step
+            if force_states is not None:
+                current = min(current, int(mask_index.sum()))      # forced states need not follow this run's own counts
+            left_tokens_last_step = 0
+            sel_conf, sel_idx = torch.topk(full, current)
+            transfer = torch.zeros_like(x, dtype=torch.bool)
+            transfer[0, sel_idx[0]] = True
+            for kk in range(1, current):
+                if sel_conf[0, kk] < args.threshold:
+                    if i < steps - 1:
+                        left_tokens_last_step += 1
+                        transfer[0, sel_idx[0, kk]] = False
+                    else:
+                        number_transfer_tokens = 0
+                        steps += 1
+                        left_tokens_last_step += 1
+                        transfer[0, sel_idx[0, kk]] = False
+            x[transfer] = cand[transfer].clone()
+            if trace:
+                tr.conf.append(conf.clone()); tr.x0.append(x0.clone()); tr.k.append(current)
+                tr.chosen.append(transfer.nonzero()); tr.key.append(full.float()); tr.cand.append(mask_index.clone())
+                tr.gap.append(dg.get("gap", torch.zeros(0))); tr.absmax.append(dg.get("absmax", torch.zeros(0)))
+                tr.pmax.append(dg.get("pmax", torch.zeros(0)))
         else:
             if args.alg not in ("maskgit_plus", "topk_margin", "entropy"):
                 raise RuntimeError(f"Unknown alg: {args.alg}")
@@ -391,11 +436,12 @@ def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: to
 def diffusion_generate(sd, dims: Dims, input_ids: torch.Tensor, *, max_new_tokens: int, steps: int,
                        alg: str = "origin", alg_temp=None, temperature: float = 0.0, top_p=None, top_k=None,
                        eps: float = 1e-3, block_length=None, noise=None, trace: bool = False,
-                       tokens_hook=None, logits_hook=None, force_states=None, max_steps=None) -> SamplerTrace:
+                       tokens_hook=None, logits_hook=None, force_states=None, max_steps=None,
+                       threshold: float = 0.9) -> SamplerTrace:
     """Oracle twin of ``model.diffusion_generate`` for equal-length prompts."""
     args = SamplerArgs(max_length=input_ids.shape[1] + max_new_tokens, steps=steps, mask_id=dims.mask_id, eps=eps,
                        alg=alg, alg_temp=alg_temp, temperature=temperature, top_p=top_p, top_k=top_k,
-                       block_length=block_length, output_history=True)
+                       block_length=block_length, output_history=True, threshold=threshold)
     with torch.no_grad():
         return sample_loop(lambda x: forward_logits(sd, dims, x), input_ids, args, noise=noise,
                            tokens_hook=tokens_hook, logits_hook=logits_hook, trace=trace, force_states=force_states,

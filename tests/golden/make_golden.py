@@ -33,6 +33,12 @@ from CoDALanguageModel.generation_utils import (  # noqa: E402
 
 DLMGenerationConfig.validate = lambda self, *a, **k: None
 
+# the serving sampler: serving/fast-api/app/core/service.py:24 imports it as dream.model.generation_utils
+sys.path.insert(0, "/root/reference/serving")
+from dream.model.generation_utils import DreamGenerationConfig, DreamGenerationMixin  # noqa: E402
+
+DreamGenerationConfig.validate = lambda self, *a, **k: None
+
 TINY = dict(vocab=512, hidden=64, inter=128, heads=4, kv_heads=2, head_dim=16, layers=2, mask_id=511, pad_id=500,
             max_pos=4096)
 # smallest shape the HIP kernels accept (head_dim 128, K multiple of 64)
@@ -245,6 +251,59 @@ def main():
                                                     G=G, seed=seed, max_prompt_len=max_prompt_len, **c)))
         out[name + "_prompts"] = np.array(repr(plist))
         out[name + "_ids"] = ids.numpy()
+
+    # ---- G8: the serving sampler bound onto the CoDA model exactly as serving/fast-api/app/core/service.py:75-120 does
+    #          (forward adapter returning .logits + DreamGenerationMixin methods), batch 1: the FastAPI defaults
+    #          (entropy, alg_temp=0.1, T=0, config.py:35-42) and the confidence_threshold alg with its dynamic step count
+    import types
+    for name, kw, dtype, wseed in (("serve_tiny_f32", TINY, torch.float32, 51), ("serve_small_f32", SMALL, torch.float32, 52),
+                                   ("serve_small_bf16", SMALL, torch.bfloat16, 52)):
+        d = ref_cpu.Dims(**kw)
+        sd32 = ref_cpu.make_state_dict(d, wseed, torch.float32, lm_head_gain=8.0, norm_jitter=0.1)
+        sd = {k: v.to(dtype) for k, v in sd32.items()}
+        m = ref_model(d, sd32, dtype)
+        orig_forward = m.forward
+
+        def fwd(_self, *a, _f=orig_forward, **k):
+            o = _f(*a, **k)
+            return types.SimpleNamespace(logits=o[0], past_key_values=None)
+        m.forward = types.MethodType(fwd, m)
+        for meth in ("_validate_generated_length", "_prepare_generated_length", "_prepare_generation_config",
+                     "_prepare_special_tokens", "diffusion_generate", "_sample"):
+            setattr(m, meth, types.MethodType(getattr(DreamGenerationMixin, meth), m))
+        m._expand_inputs_for_generation = lambda expand_size=1, input_ids=None, attention_mask=None: \
+            DreamGenerationMixin._expand_inputs_for_generation(expand_size=expand_size, input_ids=input_ids, attention_mask=attention_mask)
+        ids = prompts(d, 1, 7, 2000 + wseed)
+        attn = torch.ones_like(ids)
+        cases = (dict(steps=8, alg="entropy", alg_temp=0.1, temperature=0.0, seed=61),
+                 dict(steps=8, alg="confidence_threshold", temperature=0.0, threshold=0.9, seed=None),
+                 dict(steps=4, alg="confidence_threshold", temperature=0.0, threshold=0.5, seed=None),
+                 dict(steps=16, alg="confidence_threshold", temperature=0.0, threshold=0.02, seed=None),
+                 dict(steps=8, alg="confidence_threshold", temperature=0.6, top_p=0.95, threshold=0.7, seed=64))
+        for ci, c in enumerate(cases):
+            c = dict(c)
+            seed, thr = c.pop("seed"), c.pop("threshold", None)
+            G = 16
+            gc = DreamGenerationConfig(mask_token_id=d.mask_id, pad_token_id=d.pad_id, eos_token_id=d.pad_id + 1, bos_token_id=d.pad_id,
+                                       return_dict_in_generate=True, output_history=True, max_new_tokens=G, **c)
+            if seed is not None:
+                torch.manual_seed(seed)
+            extra = {} if thr is None else dict(threshold=thr)
+            with torch.no_grad():
+                ref = m.diffusion_generate(inputs=ids, attention_mask=attn, generation_config=gc, **extra)
+            if seed is not None:
+                torch.manual_seed(seed)
+            tr = ref_cpu.diffusion_generate(sd, d, ids, max_new_tokens=G, **c, **extra)
+            hist = torch.stack(list(ref.history))
+            same = torch.equal(tr.sequences, ref.sequences) and len(tr.history) == len(ref.history) and torch.equal(torch.stack(tr.history), hist)
+            print(f"  {name}[{ci}] {c} thr={thr} steps used {len(ref.history)} oracle==reference: {same}")
+            assert same, "oracle diverges from the serving sampler"
+            key = f"{name}_{ci}"
+            out[key + "_ids"] = ids.numpy()
+            out[key + "_seq"] = ref.sequences.numpy()
+            out[key + "_hist"] = hist.numpy().astype(np.int32)
+            out[key + "_meta"] = np.array(repr(dict(dims=kw, dtype=str(dtype), weight_seed=wseed, gain=8.0, norm_jitter=0.1,
+                                                    G=G, seed=seed, threshold=thr, **c)))
 
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     sz = os.path.getsize(os.path.join(HERE, "reference_vectors.npz"))

@@ -65,6 +65,12 @@ def teacher_forced(sd, d, ids, hip_hist, hip_trace, noise_log=None, **kw):
     st = dict(steps=len(hip_hist), exact_steps=0, candidates=0, band_tok=0, conf_checked=0, max_conf_err=0.0,
               max_conf_err_over_tol=0.0, violations=[])
     B, L = x_init.shape
+    if alg == "confidence_threshold":
+        # the serving sampler's bookkeeping (serving/dream/model/generation_utils.py:416-465), replayed on the HIP
+        # path's own confidences: quota per step, tokens held back, and the data-dependent step count
+        thr_steps = kw["steps"]
+        thr_quota, thr_left = G // thr_steps, 0
+        threshold = kw.get("threshold", 0.9)
     for i, new in enumerate(hip_hist):
         prev, cand = states[i], tr.cand[i]
         if torch.equal(tr.history[i], new):
@@ -105,7 +111,7 @@ def teacher_forced(sd, d, ids, hip_hist, hip_trace, noise_log=None, **kw):
         # ---- confidences (only where the token agrees: with sampling the confidence is p[x0])
         ok = ~tok_bad
         conf_o = tr.conf[i].float()
-        tol = conf_tolerance(conf_o, tr.absmax[i], tr.pmax[i], alg, temperature)
+        tol = conf_tolerance(conf_o, tr.absmax[i], tr.pmax[i], "maskgit_plus" if alg == "confidence_threshold" else alg, temperature)
         err = (conf_h - conf_o).abs()
         if ok.any():
             st["conf_checked"] += int(ok.sum())
@@ -115,6 +121,22 @@ def teacher_forced(sd, d, ids, hip_hist, hip_trace, noise_log=None, **kw):
                 j = int((err / tol).masked_fill(~ok, 0).argmax())
                 st["violations"].append((i, f"confidence outside tolerance: hip {conf_h[j]:.6g} oracle {conf_o[j]:.6g} tol {tol[j]:.3g}"))
         # ---- selection, exact, from the HIP path's own confidences
+        if alg == "confidence_threshold":
+            cur = thr_quota + thr_left
+            pos = flat.tolist()
+            order = sorted(range(n), key=lambda c: (-float(conf_h[c]), pos[c]))[:cur]
+            keep = [c for r, c in enumerate(order) if r == 0 or not (float(conf_h[c]) < threshold)]
+            thr_left = len(order) - len(keep)
+            if thr_left and i >= thr_steps - 1:
+                thr_quota, thr_steps = 0, thr_steps + 1
+            expect = prev.clone().reshape(-1)
+            for c in keep:
+                expect[pos[c]] = x0_h[c]
+            if not torch.equal(expect.reshape(B, L), new):
+                st["violations"].append((i, f"threshold selection differs from the reference rule on the HIP confidences (k={cur})"))
+            if i == len(hip_hist) - 1 and thr_steps != len(hip_hist):
+                st["violations"].append((i, f"step count {len(hip_hist)} != {thr_steps} implied by the reference bookkeeping"))
+            continue
         k = tr.k[i]
         full = torch.full((B * L,), -torch.inf)
         full[flat] = conf_h

@@ -272,3 +272,47 @@ def test_lm_eval_adapter_left_padded(small, temperature):
         for r, row in zip(resp, out.sequences.cpu()):
             tail = row[10:].tolist()
             assert r == (tail[:tail.index(eos)] if eos in tail else tail)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(steps=8, temperature=0.0, threshold=0.9),
+    dict(steps=4, temperature=0.0, threshold=0.5),
+    dict(steps=16, temperature=0.0, threshold=0.02),
+    dict(steps=8, temperature=0.6, top_p=0.95, threshold=0.7),
+])
+def test_confidence_threshold_serving_alg(small, cfg):
+    """the serving sampler's confidence_threshold alg (serving/dream/model/generation_utils.py:416-465),
+    one sequence, data-dependent step count; teacher-forced against the oracle, bookkeeping replayed on HIP confidences."""
+    from coda_amd.serving import SamplerService
+    from parity import teacher_forced
+    d, sd, m = small
+    g = torch.Generator().manual_seed(52)
+    ids = torch.randint(0, d.pad_id, (1, 7), generator=g)
+    cfg = dict(cfg)
+    kw = dict(max_new_tokens=16, alg="confidence_threshold", **cfg)
+    extra, log = {}, None
+    if cfg["temperature"] > 0:
+        torch.manual_seed(99)
+        noise = ref_cpu.TorchNoise()
+        ref_cpu.diffusion_generate(sd, d, ids, noise=noise, **kw)
+        extra, log = dict(noise_source=Replay(noise.log, d.vocab)), noise.log
+    trace = []
+    out = m.diffusion_generate(ids.to(DEV), mask_token_id=d.mask_id, return_dict_in_generate=True, output_history=True,
+                               debug_trace=trace, **extra, **kw)
+    hist = [h.cpu() for h in out.history]
+    assert (out.sequences != d.mask_id).all() and len(hist) >= cfg["steps"] and len(trace) == len(hist)
+    stats, _ = teacher_forced(sd, d, ids, hist, trace, noise_log=log, **kw)
+    print(f"confidence_threshold {cfg}: {len(hist)} steps used; {stats['exact_steps']} identical, {stats['band_tok']} tok-band, "
+          f"max conf err {stats['max_conf_err']:.4g} = {stats['max_conf_err_over_tol']:.2f} x tol, {len(stats['violations'])} violations")
+    assert not stats["violations"], stats["violations"][:5]
+    if cfg["temperature"] == 0:
+        # the serving mirror returns the same completion, mask/pad ids dropped
+        svc = SamplerService(m, mask_token_id=d.mask_id)
+        got = svc.generate_ids(ids[0].tolist(), max_tokens=16, steps=cfg["steps"], alg="confidence_threshold", alg_temp=0.0,
+                               threshold=cfg["threshold"])
+        tail = out.sequences[0, 7:].cpu()
+        assert got == tail[(tail != d.mask_id) & (tail != d.pad_id)].tolist()
+    with pytest.raises(AssertionError):
+        m.diffusion_generate(ids.repeat(2, 1).to(DEV), mask_token_id=d.mask_id, **kw)           # batch size must be 1
+    with pytest.raises(AssertionError):
+        m.diffusion_generate(ids.to(DEV), mask_token_id=d.mask_id, max_new_tokens=16, steps=5, alg="confidence_threshold")

@@ -361,6 +361,37 @@ def test_select_unmask_matches_oracle(alg_temp):
         assert torch.equal(xd.cpu(), expect), trial
 
 
+def test_select_threshold_matches_reference_rule():
+    """coda_select_threshold vs the serving sampler's rule (serving/dream/model/generation_utils.py:442-465) restated
+    with torch.topk on the same confidences: the best of the k is always revealed, the others only at >= threshold."""
+    g = torch.Generator().manual_seed(15)
+    L, P, mask_id = 160, 24, 7
+    for trial, (k, thr) in enumerate(((5, 0.5), (1, 0.99), (12, 0.0), (9, 2.0), (0, 0.5), (40, 0.3))):
+        x = torch.randint(10, 50, (1, L), generator=g)
+        x[:, P:][torch.rand(1, L - P, generator=g) < 0.5] = mask_id
+        conf = torch.rand(1, L, generator=g)
+        x0 = torch.randint(100, 200, (1, L), generator=g)
+        mask_index = x == mask_id
+        k = min(k, int(mask_index.sum()))
+        full = torch.full((1, L), -torch.inf)
+        full[mask_index] = conf[mask_index]
+        sel_conf, sel_idx = torch.topk(full, k)
+        transfer = torch.zeros_like(mask_index)
+        transfer[0, sel_idx[0]] = True
+        held = 0
+        for kk in range(1, k):
+            if sel_conf[0, kk] < thr:
+                held += 1
+                transfer[0, sel_idx[0, kk]] = False
+        expect = torch.where(transfer, x0, x)
+        xd = x.to(DEV)
+        info = torch.full((2,), -7, device=DEV, dtype=torch.int32)
+        _lib.call("coda_select_threshold", _p(xd), _p(conf.to(DEV).contiguous()), _p(x0.to(DEV)), L, P, L, mask_id, k, thr, _p(info), _s())
+        torch.cuda.synchronize()
+        assert torch.equal(xd.cpu(), expect), trial
+        assert info.tolist() == [int(transfer.sum()), held], (trial, info.tolist(), int(transfer.sum()), held)
+
+
 def _lmhead(hidden, W, src, dst, cnt, cap, alg, temperature=0.0, noise=None, T_total=None, round_conf=0, seed=0):
     V, H = W.shape
     T_total = T_total or hidden.shape[0]

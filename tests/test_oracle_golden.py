@@ -179,3 +179,29 @@ def test_lm_eval_call_shape(golden, prefix):
         for r, row in zip(resp, ref_seq):
             tail = row[ids.shape[1]:].tolist()
             assert r == (tail[:tail.index(d.pad_id + 1)] if d.pad_id + 1 in tail else tail)
+
+
+@pytest.mark.parametrize("prefix", ["serve_tiny_f32", "serve_small_f32", "serve_small_bf16"])
+def test_serving_sampler_vectors(golden, prefix):
+    """The serving sampler (serving/dream/model/generation_utils.py:369-508) bound onto the reference CoDA model as
+    service.py does: FastAPI defaults and confidence_threshold, including its data-dependent number of steps."""
+    keys = _e2e_keys(golden, prefix)
+    assert len(keys) == 5
+    grew = 0
+    for key in keys:
+        meta = _meta(golden, key + "_meta")
+        d = ref_cpu.Dims(**meta["dims"])
+        sd = ref_cpu.make_state_dict(d, meta["weight_seed"], torch.float32, meta["gain"], meta["norm_jitter"])
+        sd = {k: v.to(DT[meta["dtype"]]) for k, v in sd.items()}
+        kw = {k: meta[k] for k in ("steps", "temperature", "alg", "alg_temp", "top_p") if k in meta}
+        if meta["threshold"] is not None:
+            kw["threshold"] = meta["threshold"]
+        if meta["seed"] is not None:
+            torch.manual_seed(meta["seed"])
+        tr = ref_cpu.diffusion_generate(sd, d, torch.from_numpy(golden[key + "_ids"]), max_new_tokens=meta["G"], **kw)
+        hist = torch.from_numpy(golden[key + "_hist"]).long()
+        assert len(tr.history) == hist.shape[0]
+        assert torch.equal(torch.stack(tr.history), hist)
+        assert torch.equal(tr.sequences, torch.from_numpy(golden[key + "_seq"]))
+        grew += hist.shape[0] > meta["steps"]
+    assert grew >= 2          # the fixtures exercise the step-count extension
