@@ -119,6 +119,8 @@ class CoDALanguageModel(DLMGenerationMixin, PreTrainedModel):
         parameters were replaced or modified in place).  Raises if libcoda_hip.so is absent or
         the model is not on a GPU: there is no PyTorch fallback."""
         from .engine import HipEngine
+        if getattr(self, "_engine_pinned", False):
+            return self._engine
         w = self.lm_head.weight
         key = (w.device, w.data_ptr(), w._version, self.model.embed_tokens.weight.data_ptr(),
                self.model.embed_tokens.weight._version)
@@ -130,8 +132,21 @@ class CoDALanguageModel(DLMGenerationMixin, PreTrainedModel):
             self._engine_key = key
         return self._engine
 
+    def pin_engine(self, engine):
+        """Adopts an engine whose packed weights are the ONLY copy (coda_amd.checkpoint.load_packed: the module tree is
+        on the meta device); ``device`` then reports the engine's GPU."""
+        self._engine, self._engine_pinned = engine, True
+
+    @property
+    def device(self):
+        if getattr(self, "_engine_pinned", False):
+            return self._engine.device
+        return super().device
+
     def refresh_engine(self):
         """Drops the packed weights (call after editing parameters other than lm_head / embeddings in place)."""
+        if getattr(self, "_engine_pinned", False):
+            raise _lib.CodaHipError("this model's weights exist only in its packed engine (load_packed); reload the checkpoint instead")
         self._engine = None
 
     def forward(self, input_ids: torch.LongTensor, labels=None, attention_mask=None, src_mask=None,

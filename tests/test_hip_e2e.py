@@ -316,3 +316,34 @@ def test_confidence_threshold_serving_alg(small, cfg):
         m.diffusion_generate(ids.repeat(2, 1).to(DEV), mask_token_id=d.mask_id, **kw)           # batch size must be 1
     with pytest.raises(AssertionError):
         m.diffusion_generate(ids.to(DEV), mask_token_id=d.mask_id, max_new_tokens=16, steps=5, alg="confidence_threshold")
+
+
+def test_load_packed_checkpoint_equals_module_path(small, tmp_path):
+    """safetensors (sharded) -> fused HBM layouts directly; the nn.Module tree holds no storage and the
+    generated tokens equal those of the same weights loaded through the ordinary parameter path."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    from coda_amd import checkpoint
+    d, sd, m = small
+    raw = str(tmp_path)
+    keys = list(sd)
+    wm = {}
+    for i, ks in enumerate((keys[0::2], keys[1::2])):
+        fn = f"model-{i + 1:05d}-of-00002.safetensors"
+        save_file({k: sd[k].contiguous() for k in ks}, os.path.join(raw, fn))
+        wm.update({k: fn for k in ks})
+    json.dump({"metadata": {}, "weight_map": wm}, open(os.path.join(raw, checkpoint.INDEX_NAME), "w"))
+    m.config.save_pretrained(raw)
+    packed = checkpoint.load_packed(raw, device=DEV)
+    assert all(p.device.type == "meta" for p in packed.parameters())
+    assert packed.device.type == "cuda"
+    g = torch.Generator().manual_seed(9)
+    ids = torch.randint(0, d.pad_id, (3, 12), generator=g).to(DEV)
+    kw = dict(max_new_tokens=24, steps=12, alg="entropy", mask_token_id=d.mask_id, block_length=8)
+    a = m.diffusion_generate(ids, **kw)
+    b = packed.diffusion_generate(ids, **kw)
+    assert torch.equal(a, b)
+    la, _ = m(ids)
+    lb, _ = packed(ids)
+    assert torch.equal(la, lb)
