@@ -79,13 +79,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # CODA_BENCH_BACKEND=gloo rehearses the N>1 code path on a box with fewer GPUs than ranks (ranks then share GPUs);
+    # the driver's runs use the default: RCCL, one rank per GPU
+    backend = os.environ.get("CODA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from coda_amd import CoDAConfig, CoDALanguageModel
     from coda_amd.profiling import KernelTimer
@@ -131,7 +139,7 @@ def main():
     dt = time.perf_counter() - t0
     eng.timer = None
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 

@@ -23,6 +23,9 @@ def gather_completions(local: torch.Tensor, dist=None, n_total: Optional[int] = 
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world = dist.get_world_size()
+    home = local.device
+    if local.is_cuda and dist.get_backend() == "gloo":
+        local = local.cpu()                      # gloo has no device all_gather (CPU rehearsals of the GPU path)
     sizes = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes)
@@ -33,7 +36,7 @@ def gather_completions(local: torch.Tensor, dist=None, n_total: Optional[int] = 
         padded = torch.cat([local, local.new_zeros(bmax - local.shape[0], local.shape[1])], dim=0)
     out = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(out, padded.contiguous())
-    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0).to(home)
 
 
 def generate_data_parallel(generate: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.Tensor, dist=None):
