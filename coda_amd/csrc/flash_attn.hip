@@ -1,8 +1,10 @@
 // Non-causal, mask-free GQA flash attention forward for head_dim 128 on CDNA4 MFMA.
 // Replaces attention.py:12-90 of the reference (repeat_kv + SDPA(is_causal=False), no mask: SURVEY F3).
 //
-// Work split: one workgroup = 4 waves = 128 queries of one (batch, q head); each wave owns 32
-// queries.  K/V tiles of 64 keys are streamed through a double-buffered LDS ring by LDS-DMA.
+// Work split: one workgroup = 4 waves; it walks query blocks qs, qs + qsplit, ... (128 queries each, 32 per
+// wave) of one (batch, q head).  K/V tiles of 64 keys are streamed through a double-buffered LDS ring by
+// LDS-DMA; the ring and the Q prefetch run CONTINUOUSLY across query blocks, so the fixed cost of a workgroup
+// (launch, first Q/K/V fetch: ~10 us, 44 % of the time at L = 384 with one block per workgroup) is paid once.
 //
 // MFMA orientation (v_mfma_f32_32x32x16_bf16 everywhere):
 //   S^T[key][query] = K Q^T   A = K rows from LDS (ds_read_b128), B = Q^T held in registers.
@@ -17,6 +19,7 @@
 // ch ^ (((r&3)<<2) | ((r>>2)&3)): conflict-free for the b128 row reads and the transposed reads.
 #include "coda_abi_internal.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -30,6 +33,7 @@ struct AttnArgs {
     const char* qkv; long long ld_b;
     char* out; long long ldo_b;
     int B, L, n_q, n_kv;
+    int qsplit;                  // workgroups per (batch, head): block qs handles query blocks qs, qs + qsplit, ...
     float scale_log2e;
 };
 
@@ -39,7 +43,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int qblk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    // XCD-aware linear order: the (n_q / n_kv) query heads x query blocks that read one K/V head are consecutive
+    // logical ids, so they run on ONE XCD at about the same time and the K/V head is fetched into that L2 once
+    // (round-robin dispatch would otherwise spread them over 6 XCDs = 6 HBM/Infinity-Cache reads of every K/V byte)
+    const int nqb = (a.L + QB - 1) / QB;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int qs = id % a.qsplit, head = (id / a.qsplit) % a.n_q, b = id / (a.qsplit * a.n_q);
     const int kvh = head / (a.n_q / a.n_kv);
     const int L = a.L;
     const char* base = a.qkv + (size_t)b * L * a.ld_b;
@@ -47,14 +56,14 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnArgs a) {
     const char* vbase = base + (size_t)(a.n_q + a.n_kv + kvh) * 256;
 
     // ---- Q^T fragments: lane (query c, half h), k-step ks: Q[q][16 ks + 8 h .. +7]
-    const int q_row = qblk * QB + wave * 32 + c;
-    const int q_ld = min(q_row, L - 1);
     bf16x8_t qf[8];
-    {
+    auto load_q = [&](int qblk, bf16x8_t (&q)[8]) {
+        const int q_ld = min(qblk * QB + wave * 32 + c, L - 1);
         const char* qp = base + (size_t)q_ld * a.ld_b + (size_t)head * 256 + h * 16;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8_t*)(qp + ks * 32);
-    }
+        for (int ks = 0; ks < 8; ++ks) q[ks] = *(const bf16x8_t*)(qp + ks * 32);
+    };
+    load_q(qs, qf);
 
     // ---- LDS-DMA source addressing: instruction i of this wave fills rows (i*4 + wave)*4 .. +3
     const int dma_r = lane >> 4;                                   // row within the 4-row piece
@@ -73,11 +82,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnArgs a) {
     };
 
     f32x16_t oacc[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+    float m_run, l_run;
 
     // per-lane LDS read offsets
     //  K row read (A operand of S^T): row = 32*kt2 + c, chunk = 2*ks + h
@@ -126,11 +131,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnArgs a) {
     };
 
     // One K/V tile.  Fragment reads are issued one batch ahead of the MFMAs that consume them
-    // (register double buffers kA/kB, vA/vB); MASK is only instantiated for a ragged last tile.
-    auto tile = [&](int t, auto mask_tag) {
-        constexpr bool MASK = decltype(mask_tag)::value;
-        const char* kt = lds + (t & 1) * TILE;
-        const char* vt = lds + (2 + (t & 1)) * TILE;
+    // (register double buffers kA/kB, vA/vB); the key mask runs only on a ragged last tile.
+    auto tile = [&](int t, int buf, int next_qblk, bool ragged) {
+        const char* kt = lds + buf * TILE;
+        const char* vt = lds + (2 + buf) * TILE;
         bf16x8_t kA[4], kB[4], vA[4], vB[4];
         f32x16_t s[2];
 #pragma unroll
@@ -152,14 +156,22 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnArgs a) {
         lgkm0(); load_v(vt, 0, vA);                 // first V batch flies under the last QK MFMAs and the softmax
 #pragma unroll
         for (int j = 0; j < 4; ++j) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kB[j], qf[4 + j], s[1], 0, 0, 0);
+        // Q of this block is dead from here on: on the block's last tile the next block's Q is fetched into the
+        // same registers, under the softmax, the PV product and the epilogue
+        __builtin_amdgcn_sched_barrier(0);            // keep the scheduler from hoisting these loads over the QK MFMAs
+        if (next_qblk >= 0) load_q(next_qblk, qf);
+        __builtin_amdgcn_sched_barrier(0);
 
-        if constexpr (MASK) {
+        if (ragged) {                                   // uniform branch: only a sequence's last, partial tile
+            asm volatile("" ::: "memory");              // not speculatable: keeps the branch from being if-converted
+            const int lim = L - t * KB - 4 * h;
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int key = t * KB + 32 * k2 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (key >= L) s[k2][i] = -1e30f;
+                    // key = t*KB + 4h + (32 k2 + (i&3) + 8 (i>>2)); compare the compile-time part against one
+                    // register (keeps 32 per-lane key indices from being hoisted out of the tile loop)
+                    if (32 * k2 + (i & 3) + 8 * (i >> 2) >= lim) s[k2][i] = -1e30f;
                 }
         }
         // ---- online softmax in the log2 domain (per query = per lane column; the two halves hold disjoint keys).
@@ -213,32 +225,56 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnArgs a) {
 
     const int nt = (L + KB - 1) / KB;
     const int n_full = L / KB;                     // tiles without a ragged edge
+    int gt = 0;                                    // tiles consumed so far: the ring position
     stage(0, 0);
-    for (int t = 0; t < n_full; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
-        tile(t, std::false_type{});
-    }
-    if (n_full < nt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        tile(n_full, std::true_type{});
-    }
+    for (int qblk = qs; qblk < nqb; qblk += a.qsplit) {
+        const bool more = qblk + a.qsplit < nqb;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
+        m_run = -1e30f;
+        l_run = 0.f;
+        for (int t = 0; t < nt; ++t) {
+            // the next tile's DMA must have landed.  On the first tile of a later block the 8 youngest vector-memory
+            // operations are the previous block's output stores (or, for a wave that stored nothing, its Q
+            // prefetch, which the compiler waits for before use): they may stay in flight, the DMA is older
+            if (t == 0 && qblk != qs) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + 1 < nt) {
+                stage(t + 1, (gt + 1) & 1);
+            } else if (more) {
+                stage(0, (gt + 1) & 1);            // same K/V head: the next block starts again at key tile 0
+            }
+            const int nq = (t + 1 == nt && more) ? qblk + a.qsplit : -1;
+            tile(t, gt & 1, nq, t >= n_full);
+            ++gt;
+        }
 
-    // ---- epilogue: normalise, store bf16.  reg i of d-block db: d = 32 db + (i&3) + 8 (i>>2) + 4 h
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    if (q_row < L) {
-        char* op = a.out + ((size_t)b * L + q_row) * a.ldo_b + (size_t)head * 256;
+        // ---- epilogue: normalise, store bf16.  reg i of d-block db: d = 32 db + (i&3) + 8 (i>>2) + 4 h, i.e. a
+        // lane holds 4 consecutive features per group g and its partner lane (other half h) the next 4.  The halves
+        // trade groups with v_permlane32_swap so every lane stores 8 consecutive features (16 B): half as many
+        // store instructions in the store-issue-bound tail.
+        const int q_row = qblk * QB + wave * 32 + c;
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        char* op = a.out + ((size_t)b * L + min(q_row, L - 1)) * a.ldo_b + (size_t)head * 256;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = 32 * db + 8 * g + 4 * h;
-                u32x2_t v = {pack_bf16x2(oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv),
-                             pack_bf16x2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv)};
-                *(u32x2_t*)(op + d * 2) = v;
+            for (int j = 0; j < 2; ++j) {
+                const int gA = 2 * j, gB = 2 * j + 1;
+                const unsigned a0 = pack_bf16x2(oacc[db][4 * gA] * inv, oacc[db][4 * gA + 1] * inv);
+                const unsigned a1 = pack_bf16x2(oacc[db][4 * gA + 2] * inv, oacc[db][4 * gA + 3] * inv);
+                const unsigned b0 = pack_bf16x2(oacc[db][4 * gB] * inv, oacc[db][4 * gB + 1] * inv);
+                const unsigned b1 = pack_bf16x2(oacc[db][4 * gB + 2] * inv, oacc[db][4 * gB + 3] * inv);
+                // swap: lanes 32..63 of the first operand <-> lanes 0..31 of the second
+                const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                const u32x4_t v = {s0[0], s1[0], s0[1], s1[1]};
+                const int d = 32 * db + 8 * (2 * j + h);
+                if (q_row < L) *(u32x4_t*)(op + d * 2) = v;
             }
     }
 }
@@ -249,9 +285,9 @@ extern "C" int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void
                                          int n_q, int n_kv, float scale, void* stream) {
     if (B <= 0 || L <= 0 || n_q <= 0 || n_kv <= 0 || n_q % n_kv) return CODA_ERR_SHAPE;
     if (ld_qkv < (long long)(n_q + 2 * n_kv) * 128 || ld_out < (long long)n_q * 128) return CODA_ERR_SHAPE;
-    if (B > 65535 || n_q > 65535) return CODA_ERR_SHAPE;
+    if ((long long)B * n_q * ((L + QB - 1) / QB) > 0x7fffffffLL) return CODA_ERR_SHAPE;
     if (!qkv || !out) return CODA_ERR_ARG;
-    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 7) || (ld_qkv * 2) % 16 || (ld_out * 2) % 8) return CODA_ERR_ALIGN;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || (ld_qkv * 2) % 16 || (ld_out * 2) % 16) return CODA_ERR_ALIGN;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)flash_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS) != hipSuccess)
@@ -263,7 +299,30 @@ extern "C" int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void
     a.out = (char*)out; a.ldo_b = ld_out * 2;
     a.B = B; a.L = L; a.n_q = n_q; a.n_kv = n_kv;
     a.scale_log2e = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(flash_attn_kernel, dim3((L + QB - 1) / QB, n_q, B), dim3(256), ATTN_LDS, (hipStream_t)stream, a);
+    // workgroups per (batch, head): few enough that each amortises its fixed cost over several query blocks, many
+    // enough to fill 2 workgroups per CU in whole rounds.  Cost model (us, measured on this kernel): a round costs
+    // 9.7 + 1.95 per K/V tile per query block
+    static int slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 0;
+        slots = 512;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            slots = 2 * cus;
+    }
+    const int nqb = (L + QB - 1) / QB, ntile = (L + KB - 1) / KB;
+    double best = 1e30;
+    a.qsplit = 1;
+    for (int qsp = 1; qsp <= nqb; ++qsp) {
+        const long long wgs = (long long)B * n_q * qsp;
+        const double rounds = (double)((wgs + slots - 1) / slots);
+        const double cost = rounds * (9.7 + 1.95 * ntile * ((nqb + qsp - 1) / qsp));
+        if (cost < best) { best = cost; a.qsplit = qsp; }
+    }
+    if (const char* e = getenv("CODA_ATTN_QSPLIT")) {            // A/B benches only
+        const int v = atoi(e);
+        if (v > 0) a.qsplit = v < nqb ? v : nqb;
+    }
+    hipLaunchKernelGGL(flash_attn_kernel, dim3(a.qsplit * n_q * B), dim3(256), ATTN_LDS, (hipStream_t)stream, a);
     CODA_CHECK_LAUNCH("flash_attn");
     return CODA_OK;
 }

@@ -245,7 +245,9 @@ def test_fused_qkv_rope_equals_two_call_path(B, L, n_q, n_kv, K):
     assert (out.cpu()[:, : n_q * d] == want).float().mean() > 0.995
 
 
-@pytest.mark.parametrize("B,L,n_q,n_kv", [(1, 64, 2, 1), (2, 100, 4, 2), (1, 384, 16, 8), (1, 517, 2, 2)])
+# the last two shapes make a workgroup walk several query blocks (qsplit 1 of 3 blocks with a ragged tail; 2 of 4)
+@pytest.mark.parametrize("B,L,n_q,n_kv", [(1, 64, 2, 1), (2, 100, 4, 2), (1, 384, 16, 8), (1, 517, 2, 2), (32, 300, 16, 8),
+                                          (16, 512, 16, 8)])
 def test_flash_attention(B, L, n_q, n_kv):
     g = torch.Generator().manual_seed(11)
     d, T = 128, B * L

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Times the flash attention kernel on the decoder's shapes (random data)."""
+"""Times the flash attention kernel on the decoder's shapes (random data).  QSPLITS=1,2,4 additionally forces the
+number of workgroups per (batch, head) through CODA_ATTN_QSPLIT, interleaved in one process (A/B)."""
 import math
 import os
 import sys
@@ -10,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from coda_amd import _lib  # noqa: E402
 
 _lib.load()
+splits = [0] + [int(v) for v in os.environ.get("QSPLITS", "").split(",") if v]
 for B, L in ((32, 384), (64, 768), (8, 2048)):
     n_q, n_kv, d = 16, 8, 128
     T = B * L
@@ -27,15 +29,23 @@ for B, L in ((32, 384), (64, 768), (8, 2048)):
     v = qkv[:L, (n_q + n_kv) * d:(n_q + n_kv) * d + d].float()
     ref = torch.softmax(q @ k.t() / math.sqrt(d), -1) @ v
     err = (out[:L, :d].float() - ref).abs().max().item()
-    ts = []
+    times = {s: [] for s in splits}
     for _ in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
+        for s in splits:
+            if s:
+                os.environ["CODA_ATTN_QSPLIT"] = str(s)
+            else:
+                os.environ.pop("CODA_ATTN_QSPLIT", None)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             run()
-        e1.record()
-        torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1) / 20)
-    med = sorted(ts)[2]
+            e0.record()
+            for _ in range(20):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            times[s].append(e0.elapsed_time(e1) / 20)
+    os.environ.pop("CODA_ATTN_QSPLIT", None)
     fl = 4.0 * L * L * d * n_q * B
-    print(f"attn B={B} L={L}: {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF  max err vs fp32 {err:.2e}", flush=True)
+    for s in splits:
+        med = sorted(times[s])[2]
+        print(f"attn B={B} L={L} qsplit={s or 'auto'}: {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF  max err vs fp32 {err:.2e}", flush=True)
