@@ -12,6 +12,7 @@ from coda_amd import _lib  # noqa: E402
 
 _lib.load()
 splits = [0] + [int(v) for v in os.environ.get("QSPLITS", "").split(",") if v]
+KNOB = os.environ.get("KNOB", "CODA_ATTN_QSPLIT")
 for B, L in ((32, 384), (64, 768), (8, 2048)):
     n_q, n_kv, d = 16, 8, 128
     T = B * L
@@ -33,9 +34,9 @@ for B, L in ((32, 384), (64, 768), (8, 2048)):
     for _ in range(5):
         for s in splits:
             if s:
-                os.environ["CODA_ATTN_QSPLIT"] = str(s)
+                os.environ[KNOB] = str(s)
             else:
-                os.environ.pop("CODA_ATTN_QSPLIT", None)
+                os.environ.pop(KNOB, None)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             run()
             e0.record()
@@ -44,8 +45,8 @@ for B, L in ((32, 384), (64, 768), (8, 2048)):
             e1.record()
             torch.cuda.synchronize()
             times[s].append(e0.elapsed_time(e1) / 20)
-    os.environ.pop("CODA_ATTN_QSPLIT", None)
+    os.environ.pop(KNOB, None)
     fl = 4.0 * L * L * d * n_q * B
     for s in splits:
         med = sorted(times[s])[2]
-        print(f"attn B={B} L={L} qsplit={s or 'auto'}: {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF  max err vs fp32 {err:.2e}", flush=True)
+        print(f"attn B={B} L={L} {KNOB}={s or 'auto'}: {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF  max err vs fp32 {err:.2e}", flush=True)
