@@ -27,6 +27,31 @@ extern "C" int coda_embed_gather(const long long* ids, const void* table, void* 
     return CODA_OK;
 }
 
+// ------------------------------------------------------------------ candidate-row compaction
+// generation_utils.py:462 (`logits[mask_index]`): the hidden rows of the count[0] candidates, packed
+__global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ src, long long ld_src_b, const int* __restrict__ rows,
+                                                          const int* __restrict__ count, int max_rows, char* __restrict__ dst,
+                                                          long long ld_dst_b, int chunks) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = count ? min(count[0], max_rows) : max_rows;
+    if (i >= n) return;
+    const u32x4_t* s = (const u32x4_t*)(src + (size_t)rows[i] * ld_src_b);
+    u32x4_t* d = (u32x4_t*)(dst + (size_t)i * ld_dst_b);
+    for (int c = lane; c < chunks; c += 64) d[c] = s[c];
+}
+
+extern "C" int coda_gather_rows(const void* src, long long ld_src, const int* rows, const int* count, int max_rows, void* dst,
+                                long long ld_dst, int H, void* stream) {
+    if (max_rows <= 0 || H <= 0 || H % 8 || ld_src < H || ld_dst < H) return CODA_ERR_SHAPE;
+    if (!src || !rows || !dst) return CODA_ERR_ARG;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) || (ld_src * 2) % 16 || (ld_dst * 2) % 16) return CODA_ERR_ALIGN;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((max_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const char*)src, ld_src * 2,
+                       rows, count, max_rows, (char*)dst, ld_dst * 2, H / 8);
+    CODA_CHECK_LAUNCH("gather_rows");
+    return CODA_OK;
+}
+
 // ------------------------------------------------------------------ RMSNorm
 // modeling_coda.py:36-41: y = w * bf16(x_f32 * rsqrt(mean(x_f32^2) + eps)), product rounded to bf16.
 __device__ __forceinline__ void unpack8(const u32x4_t v, float (&f)[8]) {

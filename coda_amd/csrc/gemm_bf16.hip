@@ -12,6 +12,7 @@ enum { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_F32 = 3, EPI_QKROPE 
 
 struct GemmArgs {
     const char* X; long long ldx_bytes; const int* x_rows;   // x_rows: optional row gather (nullable)
+    const int* m_count;                                      // optional device-side row count: M = min(M, m_count[0])
     const char* W; long long ldw_bytes;
     char* C; long long ldc_bytes;
     const char* R; long long ldr_bytes;
@@ -135,6 +136,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     const int tm = gm0 + (id % per_group) % gsz;
     const int tn = (id % per_group) / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
+    if (a.m_count) {                          // tile geometry stays the host's upper bound; rows beyond the count do no work
+        a.M = min(a.M, a.m_count[0]);
+        if (m0 >= a.M) return;
+    }
 
     Frag f;
     const int ch = dma_chunk(lane) * 16;
@@ -355,6 +360,11 @@ template <int EPI, int MTH>
 __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
     using T = tile256::Tile<MTH>;
     static_assert(EPI != EPI_QKROPE || MTH == 4, "the fused q/k epilogue is written for 256-token tiles");
+    if (a.m_count) {                          // device-side row count: shrink the problem before any tile is walked
+        a.M = min(a.M, a.m_count[0]);
+        if (a.M <= 0) return;
+        a.tiles_m = (a.M + T::BM - 1) / T::BM;
+    }
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -679,7 +689,7 @@ static int pick_engine(const GemmArgs& a) {
     // per-lane 32-bit DMA offsets: the operand panels of one launch must span < 4 GiB
     if ((size_t)a.M * a.ldx_bytes >= 0xffffffffull || (size_t)a.N * a.ldw_bytes >= 0xffffffffull) return 0;
     if (g_gemm_variant == 1) return 0;
-    if (g_gemm_variant >= 2) return g_gemm_variant;
+    if (g_gemm_variant >= 2 && !(a.m_count && (g_gemm_variant == 2 || g_gemm_variant == 4))) return g_gemm_variant;
     if (a.M < 256 || a.N < 128) return 0;
     // one 512-thread workgroup per CU: prefer the engine whose tile count fills whole rounds of 256 CUs
     auto fill = [](long tiles) { const long rounds = (tiles + 255) / 256; return (double)tiles / (double)(rounds * 256); };
@@ -688,6 +698,7 @@ static int pick_engine(const GemmArgs& a) {
     const long t192 = (long)((a.M + 191) / 192) * ((a.N + 255) / 256);
     if (a.N >= 256 && t256 >= 200 && fill(t256) >= 0.85) return 3;
     if (a.N >= 256 && t192 >= 200 && fill(t192) >= 0.85) return 5;    // e.g. 12288 x 2048: 512 tiles = 2 full rounds
+    if (a.m_count) return a.N >= 256 && t256 >= 200 ? 3 : 0;     // counted launches: engines that read m_count
     if (t128 >= 200 && fill(t128) >= 0.85) return 4;
     return 0;
 }
@@ -747,6 +758,26 @@ extern "C" int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, c
     }
 }
 
+
+// Plain projection whose row count lives on the device (the candidate rows of the top-p / top-k path:
+// generation_utils.py:462 + modeling_coda.py:411 restricted to `logits[mask_index]`).
+extern "C" int coda_gemm_bf16_counted(const void* X, long long ldx, const int* m_count, const void* W, long long ldw, void* C,
+                                      long long ldc, int M_max, int N, int K, void* stream) {
+    if (M_max <= 0 || N <= 0 || K <= 0 || K % BK != 0 || N % 4 != 0) return CODA_ERR_SHAPE;
+    if (!X || !W || !C || !m_count) return CODA_ERR_ARG;
+    if (((uintptr_t)X | (uintptr_t)W) & 15 || (ldx * 2) % 16 || (ldw * 2) % 16) return CODA_ERR_ALIGN;
+    if (((uintptr_t)C) & 7 || (ldc * 2) % 8) return CODA_ERR_ALIGN;
+    GemmArgs a{};
+    a.X = (const char*)X; a.ldx_bytes = ldx * 2; a.x_rows = nullptr; a.m_count = m_count;
+    a.W = (const char*)W; a.ldw_bytes = ldw * 2;
+    a.C = (char*)C; a.ldc_bytes = ldc * 2;
+    a.M = M_max; a.N = N; a.K = K;
+    a.tiles_m = (M_max + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
+    const int engine = pick_engine(a);
+    if (engine == 5) return launch192x256p<EPI_PLAIN>(a, (hipStream_t)stream);
+    if (engine == 3) return launch256p<EPI_PLAIN>(a, (hipStream_t)stream);
+    return launch<EPI_PLAIN>(a, (hipStream_t)stream);
+}
 
 // QKV projection with the q/k RMSNorm + rotary embedding fused into the epilogue (one launch instead of
 // coda_gemm_bf16 + coda_qknorm_rope).  W must be packed with coda_amd.engine.permute_qk_rows.

@@ -190,8 +190,17 @@ class HipEngine:
 
     def candidate_logits(self, max_rows: int) -> torch.Tensor:
         """Materialises bf16 logits [max_rows, V] of the candidate rows (top-p / top-k path)."""
-        out = torch.empty(max_rows, self.V, device=self.device, dtype=torch.bfloat16)
-        self._gemm("lm_head_rows", self.hn, self.lm_head, out, _lib.EPI_PLAIN, rows=self.src_rows, M=max_rows)
+        if getattr(self, "_cand_shape", None) != max_rows:
+            # resident for the generation: compacted hidden rows and their logits (top-p / top-k read them several times)
+            self._cand_hidden = torch.empty(max_rows, self.H, device=self.device, dtype=torch.bfloat16)
+            self._cand_logits = torch.empty(max_rows, self.V, device=self.device, dtype=torch.bfloat16)
+            self._cand_shape = max_rows
+        hc, out = self._cand_hidden, self._cand_logits
+        _lib.call("coda_gather_rows", _ptr(self.hn), self.hn.stride(0), _ptr(self.src_rows), _ptr(self.count), max_rows,
+                  _ptr(hc), hc.stride(0), self.H, self._stream())
+        # only count[0] rows are projected (the candidate set shrinks every step; max_rows bounds the launch)
+        _lib.call("coda_gemm_bf16_counted", _ptr(hc), hc.stride(0), _ptr(self.count), _ptr(self.lm_head), self.lm_head.stride(0),
+                  _ptr(out), out.stride(0), max_rows, self.V, self.H, self._stream())
         return out
 
     def confidence_from_logits(self, logits: torch.Tensor, alg: int, temperature: float, top_p, top_k, noise, seed: int,

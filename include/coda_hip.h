@@ -78,6 +78,16 @@ int coda_qkv_proj_rope(const void* X, long long ldx, const void* W, long long ld
                        const void* q_weight, const void* k_weight, const void* cos, const void* sin, int T, int L, int n_q,
                        int n_kv, int K, float eps, void* stream);
 
+/* Candidate-row compaction and the projection over a device-side row count: the two halves of
+ * `logits[mask_index]` (generation_utils.py:462) when logits must be materialised (top-p, top-k).
+ * coda_gather_rows: dst[i] = src[rows[i]] for i < min(count[0], max_rows) (count NULL: all), H bf16 per row.
+ * coda_gemm_bf16_counted: C[m, :] = bf16(X[m] W^T) for m < min(m_count[0], M_max); rows beyond are not
+ * touched.  M_max only bounds the launch. */
+int coda_gather_rows(const void* src, long long ld_src, const int* rows, const int* count, int max_rows, void* dst,
+                     long long ld_dst, int H, void* stream);
+int coda_gemm_bf16_counted(const void* X, long long ldx, const int* m_count, const void* W, long long ldw, void* C,
+                           long long ldc, int M_max, int N, int K, void* stream);
+
 /* Non-causal, mask-free GQA flash attention.  Replaces attention.py:12-90 (repeat_kv + SDPA with
  * is_causal=False and no mask).  Reads q/k/v from the fused QKV activation
  * (layout as above), writes out bf16 [T, n_q*128] (token-major, heads concatenated: what o_proj

@@ -136,6 +136,28 @@ def test_gemm_residual_and_gather():
     assert torch.equal(out, X.float()[rows.long()] @ W.float().t())
 
 
+@pytest.mark.parametrize("T,H,cap,cnt,N", [(700, 128, 300, 77, 520), (4096, 256, 2048, 1500, 8192), (4096, 256, 2048, 2048, 8192),
+                                          (4096, 256, 2048, 1, 8192)])
+def test_gather_rows_and_counted_gemm(T, H, cap, cnt, N):
+    """`logits[mask_index]` in two steps: compaction of the candidate rows, projection over a device-side row count
+    (the second shape takes the persistent 256x256 engine, the first the 128x128 one); integer data: exact."""
+    hidden = int_mat((T, H), -3, 3, 51).to(DEV)
+    W = int_mat((N, H), -2, 2, 52).to(DEV)
+    g = torch.Generator().manual_seed(53)
+    rows = torch.randint(0, T, (cap,), generator=g).to(torch.int32).to(DEV)
+    count = torch.tensor([cnt], dtype=torch.int32, device=DEV)
+    hc = torch.full((cap, H), 7.0, device=DEV, dtype=BF)
+    _lib.call("coda_gather_rows", _p(hidden), H, _p(rows), _p(count), cap, _p(hc), H, H, _s())
+    out = torch.full((cap, N), 9.0, device=DEV, dtype=BF)
+    _lib.call("coda_gemm_bf16_counted", _p(hc), H, _p(count), _p(W), H, _p(out), N, cap, N, H, _s())
+    torch.cuda.synchronize()
+    assert torch.equal(hc[:cnt].cpu(), hidden.cpu()[rows.cpu().long()[:cnt]])
+    assert (hc[cnt:] == 7.0).all()                                   # rows beyond the count are not touched
+    ref = (hidden.cpu().float()[rows.cpu().long()[:cnt]] @ W.cpu().float().t()).to(BF)
+    assert torch.equal(out[:cnt].cpu(), ref)
+    assert (out[cnt:] == 9.0).all()
+
+
 def test_gemm_swiglu():
     from coda_amd.engine import interleave_gate_up
     M, I, K = 130, 192, 128
