@@ -297,9 +297,11 @@ class SamplerTrace:
 def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.Tensor,
                 args: SamplerArgs, noise=None, tokens_hook=None, logits_hook=None,
                 trace: bool = False, force_states: Optional[List[torch.Tensor]] = None,
-                max_steps: Optional[int] = None) -> SamplerTrace:
+                max_steps: Optional[int] = None, step_indices: Optional[List[int]] = None) -> SamplerTrace:
     """``logits_fn(x) -> [B, L, V]`` unshifted logits.  ``force_states[i]`` (optional) replaces
-    ``x`` at the start of step i (teacher forcing, used by per-step parity checks)."""
+    ``x`` at the start of step i (teacher forcing, used by per-step parity checks).  With
+    ``step_indices`` only those steps are walked: ``force_states[n]`` is then the state at the start of
+    step ``step_indices[n]`` (a bounded sample of a full-size run)."""
     noise = noise or TorchNoise()
     B, P = input_ids.shape
     L = args.max_length
@@ -327,14 +329,17 @@ def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: to
         assert x.shape[0] == 1, "batch size must be 1"
         number_transfer_tokens = mask_index.sum().item() // steps
         left_tokens_last_step = 0
-    i = -1
+    if step_indices is not None:
+        assert force_states is not None and len(step_indices) == len(force_states)
+    n = -1
     # teacher forcing walks exactly the given states (the threshold alg's own step count is data dependent)
-    while i + 1 < (steps if force_states is None else len(force_states)):
-        i += 1
+    while n + 1 < (steps if force_states is None else len(force_states)):
+        n += 1
+        i = n if step_indices is None else step_indices[n]
         if max_steps is not None and i >= max_steps:      # bounded sample of the loop (bench.py cpu_baseline)
             break
         if force_states is not None:
-            x = force_states[i].clone()
+            x = force_states[n].clone()
         blk, j = divmod(min(i, args.steps - 1), steps_b)
         lo, hi = P + blk * bl, P + (blk + 1) * bl
         mask_index = x == args.mask_id
@@ -437,7 +442,7 @@ def diffusion_generate(sd, dims: Dims, input_ids: torch.Tensor, *, max_new_token
                        alg: str = "origin", alg_temp=None, temperature: float = 0.0, top_p=None, top_k=None,
                        eps: float = 1e-3, block_length=None, noise=None, trace: bool = False,
                        tokens_hook=None, logits_hook=None, force_states=None, max_steps=None,
-                       threshold: float = 0.9) -> SamplerTrace:
+                       threshold: float = 0.9, step_indices=None) -> SamplerTrace:
     """Oracle twin of ``model.diffusion_generate`` for equal-length prompts."""
     args = SamplerArgs(max_length=input_ids.shape[1] + max_new_tokens, steps=steps, mask_id=dims.mask_id, eps=eps,
                        alg=alg, alg_temp=alg_temp, temperature=temperature, top_p=top_p, top_k=top_k,
@@ -445,7 +450,7 @@ def diffusion_generate(sd, dims: Dims, input_ids: torch.Tensor, *, max_new_token
     with torch.no_grad():
         return sample_loop(lambda x: forward_logits(sd, dims, x), input_ids, args, noise=noise,
                            tokens_hook=tokens_hook, logits_hook=logits_hook, trace=trace, force_states=force_states,
-                           max_steps=max_steps)
+                           max_steps=max_steps, step_indices=step_indices)
 
 
 # --------------------------------------------------------------------------- lm-eval adapter (id level)

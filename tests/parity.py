@@ -54,13 +54,16 @@ def conf_tolerance(conf_o: torch.Tensor, absmax: torch.Tensor, pmax: torch.Tenso
     return (grow + 2.0 ** -7) * base + 1e-4
 
 
-def teacher_forced(sd, d, ids, hip_hist, hip_trace, noise_log=None, **kw):
+def teacher_forced(sd, d, ids, hip_hist, hip_trace, noise_log=None, states=None, step_indices=None, **kw):
+    """``states`` / ``step_indices`` (optional): compare only the given steps - hip_hist[n] / hip_trace[n] are then the
+    HIP path's state after / trace of step step_indices[n] and states[n] its state before it (full-size sample)."""
     G = kw["max_new_tokens"]
     alg, alg_temp, temperature = kw["alg"], kw.get("alg_temp") or 0.0, kw.get("temperature") or 0.0
     x_init = F.pad(ids, (0, G), value=d.mask_id)
-    states = [x_init] + list(hip_hist[:-1])
+    if states is None:
+        states = [x_init] + list(hip_hist[:-1])
     noise = ref_cpu.ReplayNoise(noise_log) if noise_log is not None else None
-    tr = ref_cpu.diffusion_generate(sd, d, ids, force_states=states, trace=True, noise=noise, **kw)
+    tr = ref_cpu.diffusion_generate(sd, d, ids, force_states=states, trace=True, noise=noise, step_indices=step_indices, **kw)
     sel_noise = {s: t for k_, s, t in (noise_log or []) if k_ == "select"}
     st = dict(steps=len(hip_hist), exact_steps=0, candidates=0, band_tok=0, conf_checked=0, max_conf_err=0.0,
               max_conf_err_over_tol=0.0, violations=[])

@@ -205,3 +205,23 @@ def test_serving_sampler_vectors(golden, prefix):
         assert torch.equal(tr.sequences, torch.from_numpy(golden[key + "_seq"]))
         grew += hist.shape[0] > meta["steps"]
     assert grew >= 2          # the fixtures exercise the step-count extension
+
+
+def test_teacher_forced_step_subset_equals_full_walk():
+    """force_states + step_indices (the bounded full-size sample of tests/test_hip_fullsize.py) reproduces exactly
+    the corresponding steps of a full teacher-forced walk, window mode included."""
+    d = ref_cpu.Dims(vocab=512, hidden=256, inter=256, heads=2, kv_heads=1, head_dim=128, layers=1, mask_id=511, pad_id=500,
+                     max_pos=512)
+    sd = ref_cpu.make_state_dict(d, 9, torch.float32, lm_head_gain=8.0)
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(0, 500, (2, 8), generator=g)
+    kw = dict(max_new_tokens=16, steps=8, alg="entropy", block_length=8)
+    free = ref_cpu.diffusion_generate(sd, d, ids, trace=True, **kw)
+    x_init = torch.nn.functional.pad(ids, (0, 16), value=d.mask_id)
+    states = [x_init] + free.history[:-1]
+    pick = [0, 3, 4, 7]
+    sub = ref_cpu.diffusion_generate(sd, d, ids, trace=True, force_states=[states[i] for i in pick], step_indices=pick, **kw)
+    assert len(sub.history) == len(pick)
+    for n, i in enumerate(pick):
+        assert torch.equal(sub.history[n], free.history[i])
+        assert sub.k[n] == free.k[i] and torch.equal(sub.conf[n], free.conf[i]) and torch.equal(sub.cand[n], free.cand[i])
