@@ -18,6 +18,7 @@ struct GemmArgs {
     const char* R; long long ldr_bytes;
     int M, N, K;
     int tiles_m, tiles_n;
+    int wide;                       // C (and R) rows are 16-byte aligned: interior tiles may use 16-byte stores / residual loads
     // EPI_QKROPE only: q/k RMSNorm weights, rotary tables [L,128], sequence length, feature bounds of q and q|k
     const char* qn_w; const char* kn_w; const char* rope_cos; const char* rope_sin;
     int L, q_feat, qk_feat; float eps;
@@ -28,10 +29,28 @@ __device__ __forceinline__ float silu_f32(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896f));
 }
 
+// Two 8-byte pieces -> one 16-byte piece per lane (guide T21 with v_permlane16_swap).  After the 16x16x32 MFMA a lane
+// of lane-row r = lane>>4 holds features 4r..4r+3 of every 16-feature block: 8 bytes, so a row of a block is written
+// by four lanes in four-byte-pair pieces and the store tail is bound by the NUMBER of store instructions.  Given the
+// lane's pieces a (block A) and b (block B = the next 16 features), the swap trades the odd lane-rows' a with the
+// even lane-rows' b: even rows end up with A's features 4r..4r+7, odd rows with B's features 4(r-1)..4(r-1)+7 -
+// 16 contiguous bytes each, one store instead of two, same bytes, same addresses.
+__device__ __forceinline__ u32x4_t widen16(u32x2_t a, u32x2_t b) {
+    const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+    return (u32x4_t){s0[0], s1[0], s0[1], s1[1]};
+}
+// byte offset of the lane's 16-byte piece inside the 64 bytes of the block pair (A at 0, B at 32)
+__device__ __forceinline__ int widen16_offset(int lane) {
+    const int r = lane >> 4;
+    return 8 * r + ((r & 1) ? 24 : 0);
+}
+
 // Epilogue of one wave's accumulator block acc[nt][mt] (4 x MT tiles of 16 features x 16 tokens):
 // the lane owns token (lane&15) of each 16-token group and features (lane>>4)*4..+3 of each 16-feature
 // group, i.e. 8 contiguous output bytes per (nt, mt).  FULL = the whole workgroup tile is inside the
-// matrix (no bounds tests).  Rounding points follow the reference's bf16 op sequence: the projection
+// matrix (no bounds tests); FULL tiles of 16-byte aligned matrices (a.wide) go out as 16-byte pieces (widen16).
+// Rounding points follow the reference's bf16 op sequence: the projection
 // output is rounded first, then residual add / silu / gate*up each round again.
 template <int EPI, int MT, bool FULL>
 __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, const f32x4_t (&acc)[4][MT], int mrow0, int ncol0, int lane) {
@@ -42,22 +61,30 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, const f32x4_t (
         // weight rows are interleaved in blocks of 16: [gate 16 | up 16] -> even nt = gate, odd nt = up
         const int nb = ncol0 / 2 + fq;
         char* c = a.C + (size_t)mf * a.ldc_bytes + (size_t)nb * 2;
+        auto swiglu = [&](int mt, int p) -> u32x2_t {
+            const unsigned g01 = pack_bf16x2(acc[2 * p][mt][0], acc[2 * p][mt][1]);
+            const unsigned g23 = pack_bf16x2(acc[2 * p][mt][2], acc[2 * p][mt][3]);
+            const unsigned u01 = pack_bf16x2(acc[2 * p + 1][mt][0], acc[2 * p + 1][mt][1]);
+            const unsigned u23 = pack_bf16x2(acc[2 * p + 1][mt][2], acc[2 * p + 1][mt][3]);
+            float s0 = silu_f32(bf16_lo(g01)), s1 = silu_f32(bf16_hi(g01));
+            float s2 = silu_f32(bf16_lo(g23)), s3 = silu_f32(bf16_hi(g23));
+            round_bf16_pair(s0, s1);
+            round_bf16_pair(s2, s3);
+            return (u32x2_t){pack_bf16x2(s0 * bf16_lo(u01), s1 * bf16_hi(u01)), pack_bf16x2(s2 * bf16_lo(u23), s3 * bf16_hi(u23))};
+        };
+        if (FULL && a.wide) {
+            char* cw = a.C + (size_t)mf * a.ldc_bytes + (size_t)(ncol0 / 2) * 2 + widen16_offset(lane);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) *(u32x4_t*)(cw + mt * rs) = widen16(swiglu(mt, 0), swiglu(mt, 1));
+            return;
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             if (!FULL && mf + mt * 16 >= a.M) continue;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 if (!FULL && nb + p * 16 >= a.N / 2) continue;
-                const unsigned g01 = pack_bf16x2(acc[2 * p][mt][0], acc[2 * p][mt][1]);
-                const unsigned g23 = pack_bf16x2(acc[2 * p][mt][2], acc[2 * p][mt][3]);
-                const unsigned u01 = pack_bf16x2(acc[2 * p + 1][mt][0], acc[2 * p + 1][mt][1]);
-                const unsigned u23 = pack_bf16x2(acc[2 * p + 1][mt][2], acc[2 * p + 1][mt][3]);
-                float s0 = silu_f32(bf16_lo(g01)), s1 = silu_f32(bf16_hi(g01));
-                float s2 = silu_f32(bf16_lo(g23)), s3 = silu_f32(bf16_hi(g23));
-                round_bf16_pair(s0, s1);
-                round_bf16_pair(s2, s3);
-                const u32x2_t v = {pack_bf16x2(s0 * bf16_lo(u01), s1 * bf16_hi(u01)), pack_bf16x2(s2 * bf16_lo(u23), s3 * bf16_hi(u23))};
-                *(u32x2_t*)(c + mt * rs + p * 32) = v;
+                *(u32x2_t*)(c + mt * rs + p * 32) = swiglu(mt, p);
             }
         }
     } else if constexpr (EPI == EPI_F32) {
@@ -73,11 +100,46 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, const f32x4_t (
             }
         }
     } else {
-        const int nb = ncol0 + fq;
-        char* c = a.C + (size_t)mf * a.ldc_bytes + (size_t)nb * 2;
         // token groups in batches of up to 4: the batch's residual loads are all issued before its first
         // store (C may alias R: every lane reads exactly the bytes it later writes)
         constexpr int MB = MT % 4 == 0 ? 4 : 3;
+        if (FULL && a.wide) {
+            // 16-byte pieces: block pairs (nt 0,1) and (nt 2,3); the residual is loaded in the same widened layout
+            const int wo = widen16_offset(lane);
+            char* cw = a.C + (size_t)mf * a.ldc_bytes + (size_t)ncol0 * 2 + wo;
+#pragma unroll
+            for (int mb = 0; mb < MT; mb += MB) {
+                u32x4_t rv[MB][2];
+                if constexpr (EPI == EPI_RESIDUAL) {
+                    const char* r = a.R + (size_t)mf * a.ldr_bytes + (size_t)ncol0 * 2 + wo;
+                    const size_t rrs = (size_t)16 * a.ldr_bytes;
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) rv[i][q] = *(const u32x4_t*)(r + (mb + i) * rrs + q * 64);
+                }
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+                    const int mt = mb + i;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const u32x2_t pa = {pack_bf16x2(acc[2 * q][mt][0], acc[2 * q][mt][1]), pack_bf16x2(acc[2 * q][mt][2], acc[2 * q][mt][3])};
+                        const u32x2_t pb = {pack_bf16x2(acc[2 * q + 1][mt][0], acc[2 * q + 1][mt][1]),
+                                            pack_bf16x2(acc[2 * q + 1][mt][2], acc[2 * q + 1][mt][3])};
+                        u32x4_t v = widen16(pa, pb);
+                        if constexpr (EPI == EPI_RESIDUAL) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                v[e] = pack_bf16x2(bf16_lo(v[e]) + bf16_lo(rv[i][q][e]), bf16_hi(v[e]) + bf16_hi(rv[i][q][e]));
+                        }
+                        *(u32x4_t*)(cw + mt * rs + q * 64) = v;
+                    }
+                }
+            }
+            return;
+        }
+        const int nb = ncol0 + fq;
+        char* c = a.C + (size_t)mf * a.ldc_bytes + (size_t)nb * 2;
 #pragma unroll
         for (int mb = 0; mb < MT; mb += MB) {
             u32x2_t rv[MB][4];
@@ -330,8 +392,17 @@ __device__ __forceinline__ void epilogue256_qkrope(const GemmArgs& a, f32x4_t (&
             outv[mt][nt][1] = (u32x2_t){pack_bf16x2(pc[0] + pd[0], pc[1] + pd[1]), pack_bf16x2(pc[2] + pd[2], pc[3] + pd[3])};
         }
     }
-    char* orow = a.C + (size_t)mf * a.ldc_bytes + (size_t)(feat0 + 32 * qh + fq) * 2;
     const size_t rs = (size_t)16 * a.ldc_bytes;
+    if (full && a.wide) {                     // 16-byte pieces (widen16): feature blocks nt = 0, 1 are neighbours in both halves
+        char* ow = a.C + (size_t)mf * a.ldc_bytes + (size_t)(feat0 + 32 * qh) * 2 + widen16_offset(lane);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            *(u32x4_t*)(ow + mt * rs) = widen16(outv[mt][0][0], outv[mt][1][0]);
+            *(u32x4_t*)(ow + mt * rs + 128) = widen16(outv[mt][0][1], outv[mt][1][1]);
+        }
+        return;
+    }
+    char* orow = a.C + (size_t)mf * a.ldc_bytes + (size_t)(feat0 + 32 * qh + fq) * 2;
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
         if (!full && mf + mt * 16 >= a.M) continue;
@@ -455,9 +526,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
     T::template load_w<0, 0>(f, ws, p0);
     T::template load_x<0, 0>(f, xs, p0);
 
-    constexpr int EPI_VMEM = (EPI == EPI_SWIGLU ? 2 : 4) * T::MT;   // stores one wave issues per full tile
+    // stores one wave issues per full tile: 8-byte pieces, or 16-byte pieces on the widened path (epilogue_wave)
+    constexpr int ST_NARROW = (EPI == EPI_SWIGLU ? 2 : 4) * T::MT;
+    constexpr int ST_WIDE = EPI == EPI_F32 ? ST_NARROW : ST_NARROW / 2;
     int xcur = 0, wcur = 0;                   // byte offsets of the ring stages holding the current K tile
-    bool stores_in_flight = false;            // previous tile's epilogue was the unconditional (full-tile) one
+    int stores_in_flight = 0;                 // stores of the previous tile's epilogue if it was the unconditional (full-tile) one
     bool w_young = false;                     // WST == 3: a W DMA younger than what the next sync needs is in flight
     for (; Lc < ntiles; Lc += G) {
         coords(Lc, cm0, cn0);
@@ -482,11 +555,16 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
             // the next tile's DMA: the W tile one further ahead (4 instructions, 3-stage ring only) and the
             // previous output tile's epilogue stores.
             {
-                const bool st = stores_in_flight && t == 0;
-                if (WST == 3 && w_young && st) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(EPI_VMEM + 4) : "memory");
-                else if (WST == 3 && w_young) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-                else if (st) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(EPI_VMEM) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const int st = t == 0 ? stores_in_flight : 0;
+                if (WST == 3 && w_young) {
+                    if (st == ST_NARROW) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST_NARROW + 4) : "memory");
+                    else if (st == ST_WIDE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST_WIDE + 4) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                } else {
+                    if (st == ST_NARROW) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST_NARROW) : "memory");
+                    else if (st == ST_WIDE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST_WIDE) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                }
                 __builtin_amdgcn_s_barrier();
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -503,7 +581,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
         const bool full = cm0 + T::BM <= a.M && cn0 + T::BN <= a.N;
         if constexpr (EPI == EPI_QKROPE) epilogue256_qkrope(a, acc, cm0, cn0, wm, wn, wave, lane, (float*)(lds + PersistentLds<MTH>::BYTES), full);
         else epilogue_tile<EPI, T::MT>(a, acc, cm0 + wm * (T::BM / 2), cn0 + wn * 64, lane, full);
-        stores_in_flight = full;
+        stores_in_flight = full ? (a.wide && EPI != EPI_F32 ? ST_WIDE : ST_NARROW) : 0;
     }
 }
 
@@ -604,9 +682,10 @@ __global__ __launch_bounds__(512, 2) void gemm256x128p_bf16_kernel(GemmArgs a) {
     T::load_w<0, 0>(f, ws, p0);
     T::load_x<0>(f, xs, p0);
 
-    constexpr int EPI_VMEM = (EPI == EPI_SWIGLU) ? 8 : 16;
+    constexpr int ST_NARROW = (EPI == EPI_SWIGLU) ? 8 : 16;
+    constexpr int ST_WIDE = EPI == EPI_F32 ? ST_NARROW : ST_NARROW / 2;
     int cur = 0, q = 0;                       // LDS byte offset of the current stage; stream position
-    bool stores_in_flight = false;
+    int stores_in_flight = 0;
     for (; Lc < ntiles; Lc += G) {
         coords(Lc, cm0, cn0);
         f32x4_t acc[4][4];
@@ -625,11 +704,16 @@ __global__ __launch_bounds__(512, 2) void gemm256x128p_bf16_kernel(GemmArgs a) {
             // epilogue stores may stay in flight (both are younger than tile q+1's DMA)
             {
                 const bool ahead = issued > q + 2;
-                const bool st = stores_in_flight && t == 0;
-                if (ahead && st) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(EPI_VMEM + 6) : "memory");
-                else if (ahead) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-                else if (st) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(EPI_VMEM) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const int st = t == 0 ? stores_in_flight : 0;
+                if (ahead) {
+                    if (st == ST_NARROW) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST_NARROW + 6) : "memory");
+                    else if (st == ST_WIDE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST_WIDE + 6) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                } else {
+                    if (st == ST_NARROW) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST_NARROW) : "memory");
+                    else if (st == ST_WIDE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST_WIDE) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                }
                 __builtin_amdgcn_s_barrier();
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -646,7 +730,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x128p_bf16_kernel(GemmArgs a) {
         }
         const bool full = cm0 + T::BM <= a.M && cn0 + T::BN <= a.N;
         epilogue_tile<EPI, 4>(a, acc, cm0 + wm * 64, cn0 + wn * 64, lane, full);
-        stores_in_flight = full;
+        stores_in_flight = full ? (a.wide && EPI != EPI_F32 ? ST_WIDE : ST_NARROW) : 0;
     }
 }
 
@@ -677,6 +761,11 @@ static int launch192x256p(GemmArgs a, hipStream_t s) { return launch256p<EPI, 3>
 // 0 auto, 1 force 128x128, 2 force 256x256 (one tile per workgroup), 3 force persistent 256x256,
 // 4 force persistent 256x128, 5 force persistent 192x256
 static int g_gemm_variant = 0;
+static int g_gemm_wide = 1;
+extern "C" int coda_gemm_wide_stores(int on) {
+    g_gemm_wide = on ? 1 : 0;
+    return CODA_OK;
+}
 extern "C" int coda_gemm_select(int variant) {
     if (variant < 0 || variant > 5) return CODA_ERR_ARG;
     g_gemm_variant = variant;
@@ -734,6 +823,7 @@ extern "C" int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, c
     a.R = (const char*)R; a.ldr_bytes = ldr * 2;
     a.M = M; a.N = N; a.K = K;
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
+    a.wide = g_gemm_wide && (((uintptr_t)C | (uintptr_t)(ldc * esz)) & 15) == 0 && (!R || (((uintptr_t)R | (uintptr_t)(ldr * 2)) & 15) == 0);
     hipStream_t s = (hipStream_t)stream;
     const int engine = pick_engine(a);
 #define CODA_DISPATCH(fn)                                      \
@@ -773,6 +863,7 @@ extern "C" int coda_gemm_bf16_counted(const void* X, long long ldx, const int* m
     a.C = (char*)C; a.ldc_bytes = ldc * 2;
     a.M = M_max; a.N = N; a.K = K;
     a.tiles_m = (M_max + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
+    a.wide = g_gemm_wide && (((uintptr_t)C | (uintptr_t)(ldc * 2)) & 15) == 0;
     const int engine = pick_engine(a);
     if (engine == 5) return launch192x256p<EPI_PLAIN>(a, (hipStream_t)stream);
     if (engine == 3) return launch256p<EPI_PLAIN>(a, (hipStream_t)stream);
@@ -798,6 +889,7 @@ extern "C" int coda_qkv_proj_rope(const void* X, long long ldx, const void* W, l
     a.C = (char*)qkv; a.ldc_bytes = ld * 2;
     a.R = nullptr; a.ldr_bytes = 0;
     a.M = T; a.N = N; a.K = K;
+    a.wide = g_gemm_wide;                     // alignment checked above
     a.qn_w = (const char*)q_weight; a.kn_w = (const char*)k_weight;
     a.rope_cos = (const char*)cos; a.rope_sin = (const char*)sin;
     a.L = L; a.q_feat = n_q * 128; a.qk_feat = (n_q + n_kv) * 128; a.eps = eps;

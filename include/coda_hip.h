@@ -60,6 +60,9 @@ int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, const void* 
 /* Tuning/diagnostic knob: which tile engine coda_gemm_bf16 uses (0 = automatic choice by shape,
  * 1 = 128x128 engine, 2 = 256x256 engine with one tile per workgroup, 3 = persistent 256x256 engine, 4 = persistent 256x128 engine).  Results are identical up to fp32 summation order. */
 int coda_gemm_select(int variant);
+/* Diagnostic knob (A/B and tests): 0 = interior tiles store 8-byte pieces per lane, 1 (default) = 16-byte pieces after a
+ * v_permlane16_swap exchange (half as many store instructions; same bytes, same results). */
+int coda_gemm_wide_stores(int on);
 
 /* q_norm / k_norm + rotary embedding, in place on the fused QKV activation.
  * Replaces modeling_coda.py:128-148 and modeling_utils.py:70-101.

@@ -66,14 +66,17 @@ def test_gemm_exact_integer(M, N, K):
     assert torch.equal(out, ref.to(BF))
 
 
+@pytest.mark.parametrize("wide", [1, 0])
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("M,N,K,epi", [(512, 512, 64, "f32"), (768, 256, 192, "plain"), (300, 520, 128, "f32"),
                                        (1024, 768, 2048, "res"), (515, 512, 320, "res"), (8192, 5120, 128, "plain"),
                                        (8192 + 40, 4096 + 128, 64, "res")])
-def test_gemm_engines_exact_integer(variant, M, N, K, epi):
-    """Both tile engines (128x128 and 256x256, forced through coda_gemm_select) on exact integer data."""
+def test_gemm_engines_exact_integer(variant, M, N, K, epi, wide):
+    """Every tile engine (forced through coda_gemm_select) on exact integer data, with the interior tiles' stores as
+    16-byte pieces (v_permlane16_swap exchange, the default) and as 8-byte pieces."""
     lib = _lib.load()
     assert lib.coda_gemm_select(variant) == 0
+    lib.coda_gemm_wide_stores(wide)
     try:
         X, W = int_mat((M, K), -3, 3, 21), int_mat((N, K), -2, 2, 22)
         ref = X.float() @ W.float().t()
@@ -88,6 +91,7 @@ def test_gemm_engines_exact_integer(variant, M, N, K, epi):
             assert torch.equal(gemm(X.to(DEV), W.to(DEV), _lib.EPI_RESIDUAL, R=R.to(DEV)).cpu(), want)
     finally:
         lib.coda_gemm_select(0)
+        lib.coda_gemm_wide_stores(1)
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])

@@ -35,7 +35,8 @@ def main():
         R = torch.randn(M, N, device=DEV, dtype=torch.float32).to(BF) if epi == 1 else None
         outs = {}
         for v in variants:
-            lib.coda_gemm_select(v)
+            lib.coda_gemm_select(v % 100)
+            lib.coda_gemm_wide_stores(0 if v >= 100 else 1)        # variant + 100 = same engine, 8-byte stores
             C = torch.zeros(M, cols, device=DEV, dtype=BF)
             run(X, W, C, R, epi)
             torch.cuda.synchronize()
@@ -54,7 +55,8 @@ def main():
         times = {v: [] for v in variants}
         for rnd in range(5):
             for v in variants:
-                lib.coda_gemm_select(v)
+                lib.coda_gemm_select(v % 100)
+                lib.coda_gemm_wide_stores(0 if v >= 100 else 1)
                 C = torch.empty(M, cols, device=DEV, dtype=BF)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 run(X, W, C, R, epi)
@@ -70,6 +72,7 @@ def main():
             msg.append(f"v{v} {med*1e3:7.1f} us {fl/med/1e9:7.1f} TF (min {min(times[v])*1e3:.1f} us)")
         print(" | ".join(msg), flush=True)
     lib.coda_gemm_select(0)
+    lib.coda_gemm_wide_stores(1)
 
 
 if __name__ == "__main__":
