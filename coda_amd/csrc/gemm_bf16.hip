@@ -419,15 +419,18 @@ __device__ __forceinline__ void epilogue256_qkrope(const GemmArgs& a, f32x4_t (&
 // LDS-DMA stream and the fragment prefetch run CONTINUOUSLY across output-tile boundaries, so the
 // first K tiles of the next output tile are already landing while the current tile's epilogue
 // stores - no per-tile prologue bubble (worth ~8 % at K = 2048).
-template <int MTH>
+// The 192-token tile leaves LDS for ONE operand ring of three stages (its DMA then runs two K tiles ahead):
+// XDEEP = false gives it to the weights, XDEEP = true to the activations.
+template <int MTH, bool XDEEP = false>
 struct PersistentLds {
     using T = tile256::Tile<MTH>;
-    static constexpr int WST = MTH == 3 ? 3 : 2;                 // W ring depth
-    static constexpr int XR = 2 * T::X_BYTES;                    // W ring base (after the 2-stage X ring)
-    static constexpr int BYTES = XR + WST * T::W_BYTES;          // 128 KiB (256-token tile) / 144 KiB (192-token tile)
+    static constexpr int XST = XDEEP ? 3 : 2;                    // X ring depth (256-token tile + XDEEP: all 160 KiB)
+    static constexpr int WST = MTH == 3 && !XDEEP ? 3 : 2;       // W ring depth
+    static constexpr int XR = XST * T::X_BYTES;                  // W ring base (after the X ring)
+    static constexpr int BYTES = XR + WST * T::W_BYTES;          // 128 KiB (256-token tile) / 144 or 136 KiB (192-token tile)
 };
 
-template <int EPI, int MTH>
+template <int EPI, int MTH, bool XDEEP = false>
 __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
     using T = tile256::Tile<MTH>;
     static_assert(EPI != EPI_QKROPE || MTH == 4, "the fused q/k epilogue is written for 256-token tiles");
@@ -454,11 +457,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
         m0 = (gm0 + (L % per_group) % gsz) * T::BM;
         n0 = ((L % per_group) / gsz) * T::BN;
     };
-    // LDS: X ring of 2 stages, then W ring of WST stages.  The 192-token tile leaves room for a third W
-    // stage: the weight panel is the operand that comes cold from HBM (every layer has its own), so its
-    // DMA runs one K tile further ahead than the activations' (which the previous kernel left in cache).
-    constexpr int WST = PersistentLds<MTH>::WST;
-    constexpr int XR = PersistentLds<MTH>::XR;
+    // LDS: X ring of XST stages, then W ring of WST stages.  The 192-token tile leaves room for a third stage of
+    // one operand, whose DMA then runs one K tile further ahead.  Which operand is colder depends on the call site:
+    // every layer's weight panel comes from HBM once, but with K = 6144 (down_proj) it is the 151 MB activation
+    // matrix the previous kernel wrote that misses every cache (tools/cold_bench.py).
+    using PL = PersistentLds<MTH, XDEEP>;
+    constexpr int XST = PL::XST, WST = PL::WST, XR = PL::XR;
+    constexpr int YOUNG = WST == 3 ? 4 : XST == 3 ? T::X_DMA : 0;   // DMA instructions of the deeper ring's newest tile
     const int ch = tile256::dma_chunk(lane) * 16;
     unsigned xoff[T::X_DMA], woff[4];           // per-lane byte offsets of the DMA instructions of each operand
     auto set_x = [&](int m0) {
@@ -480,8 +485,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
     set_w(cn0);
     // two DMA cursors over the workgroup's stream of K tiles (output tile, K tile): the next one to stage
     int xL = Lc, xk = 0, wL = Lc, wk = 0;
-    auto dma_x = [&](char* dst) {
-        if (xL < ntiles) {
+    auto dma_x = [&](char* dst) -> bool {
+        if (xL >= ntiles) return false;
+        {
             const size_t kb = (size_t)xk * T::BK * 2;
 #pragma unroll
             for (int i = 0; i < T::X_DMA; ++i) glds16(a.X + kb + xoff[i], dst + (i * 8 + wave) * 1024);
@@ -495,6 +501,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
                 }
             }
         }
+        return true;
     };
     auto dma_w = [&](char* dst) -> bool {
         if (wL >= ntiles) return false;
@@ -512,8 +519,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
         }
         return true;
     };
-    dma_x(lds);
-    dma_x(lds + T::X_BYTES);
+#pragma unroll
+    for (int i = 0; i < XST; ++i) dma_x(lds + i * T::X_BYTES);
 #pragma unroll
     for (int i = 0; i < WST; ++i) dma_w(lds + XR + i * T::W_BYTES);
     tile256::tile_sync();
@@ -531,7 +538,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
     constexpr int ST_WIDE = EPI == EPI_F32 ? ST_NARROW : ST_NARROW / 2;
     int xcur = 0, wcur = 0;                   // byte offsets of the ring stages holding the current K tile
     int stores_in_flight = 0;                 // stores of the previous tile's epilogue if it was the unconditional (full-tile) one
-    bool w_young = false;                     // WST == 3: a W DMA younger than what the next sync needs is in flight
+    bool young = false;                       // 3-stage ring: a DMA younger than what the next sync needs is in flight
     for (; Lc < ntiles; Lc += G) {
         coords(Lc, cm0, cn0);
         f32x4_t acc[4][T::MT];
@@ -540,7 +547,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
 #pragma unroll
             for (int j = 0; j < T::MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         for (int t = 0; t < nk; ++t) {
-            const int xnxt = T::X_BYTES - xcur;
+            const int xnxt = xcur == (XST - 1) * T::X_BYTES ? 0 : xcur + T::X_BYTES;
             const int wnxt = wcur == (WST - 1) * T::W_BYTES ? 0 : wcur + T::W_BYTES;
             const char* xc = xs + xcur;
             const char* wc = ws + wcur;
@@ -552,14 +559,14 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
             tile256::phase_begin(); T::template load_x<1, 1>(f, xc, p1); T::template quad<0, 0, 0, 0>(f, acc);
             // Every wave has retired its reads of these stages, and the next K tile of the stream must have
             // landed.  vmcnt retires in order, so what may stay in flight is exactly what was issued AFTER
-            // the next tile's DMA: the W tile one further ahead (4 instructions, 3-stage ring only) and the
-            // previous output tile's epilogue stores.
+            // the next tile's DMA: the deeper ring's tile one further ahead (YOUNG instructions, issued LAST in its
+            // iteration) and the previous output tile's epilogue stores.
             {
                 const int st = t == 0 ? stores_in_flight : 0;
-                if (WST == 3 && w_young) {
-                    if (st == ST_NARROW) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST_NARROW + 4) : "memory");
-                    else if (st == ST_WIDE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST_WIDE + 4) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                if (YOUNG && young) {
+                    if (st == ST_NARROW) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST_NARROW + YOUNG) : "memory");
+                    else if (st == ST_WIDE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST_WIDE + YOUNG) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(YOUNG) : "memory");
                 } else {
                     if (st == ST_NARROW) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST_NARROW) : "memory");
                     else if (st == ST_WIDE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST_WIDE) : "memory");
@@ -568,8 +575,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
                 __builtin_amdgcn_s_barrier();
             }
             __builtin_amdgcn_sched_barrier(0);
-            dma_x(lds + xcur);
-            w_young = dma_w(lds + XR + wcur);
+            if constexpr (XST == 3) {
+                dma_w(lds + XR + wcur);
+                young = dma_x(lds + xcur);
+            } else {
+                dma_x(lds + xcur);
+                young = dma_w(lds + XR + wcur);
+            }
             T::template load_x<0, 0>(f, xs + xnxt, p0);      // first fragments of the next K tile (stale bytes after the last one: unused)
             T::template quad<0, 1, 0, 1>(f, acc);
             tile256::phase_begin();
@@ -579,20 +591,22 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
             wcur = wnxt;
         }
         const bool full = cm0 + T::BM <= a.M && cn0 + T::BN <= a.N;
-        if constexpr (EPI == EPI_QKROPE) epilogue256_qkrope(a, acc, cm0, cn0, wm, wn, wave, lane, (float*)(lds + PersistentLds<MTH>::BYTES), full);
+        if constexpr (EPI == EPI_QKROPE) epilogue256_qkrope(a, acc, cm0, cn0, wm, wn, wave, lane, (float*)(lds + PL::BYTES), full);
         else epilogue_tile<EPI, T::MT>(a, acc, cm0 + wm * (T::BM / 2), cn0 + wn * 64, lane, full);
         stores_in_flight = full ? (a.wide && EPI != EPI_F32 ? ST_WIDE : ST_NARROW) : 0;
     }
 }
 
-template <int EPI, int MTH = 4>
+template <int EPI, int MTH = 4, bool XDEEP = false>
 static int launch256p(GemmArgs a, hipStream_t s) {
     using T = tile256::Tile<MTH>;
     static bool attr_done = false;
     static int n_cu = 256;
+    constexpr int lds_bytes = PersistentLds<MTH, XDEEP>::BYTES + (EPI == EPI_QKROPE ? 4096 : 0);
+    static_assert(lds_bytes <= 160 * 1024, "LDS per CU");
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)gemm256p_bf16_kernel<EPI, MTH>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                PersistentLds<MTH>::BYTES + 4096) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)gemm256p_bf16_kernel<EPI, MTH, XDEEP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds_bytes) != hipSuccess)
             return CODA_ERR_LAUNCH;
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
@@ -602,7 +616,7 @@ static int launch256p(GemmArgs a, hipStream_t s) {
     a.tiles_m = (a.M + T::BM - 1) / T::BM;
     a.tiles_n = (a.N + T::BN - 1) / T::BN;
     const int grid = a.tiles_m * a.tiles_n < n_cu ? a.tiles_m * a.tiles_n : n_cu;
-    hipLaunchKernelGGL((gemm256p_bf16_kernel<EPI, MTH>), dim3(grid), dim3(512), PersistentLds<MTH>::BYTES + (EPI == EPI_QKROPE ? 4096 : 0), s, a);
+    hipLaunchKernelGGL((gemm256p_bf16_kernel<EPI, MTH, XDEEP>), dim3(grid), dim3(512), lds_bytes, s, a);
     CODA_CHECK_LAUNCH("gemm256p_bf16");
     return CODA_OK;
 }
@@ -757,9 +771,14 @@ static int launch256x128p(GemmArgs a, hipStream_t s) {
 
 template <int EPI>
 static int launch192x256p(GemmArgs a, hipStream_t s) { return launch256p<EPI, 3>(a, s); }
+template <int EPI>
+static int launch192x256px(GemmArgs a, hipStream_t s) { return launch256p<EPI, 3, true>(a, s); }
+template <int EPI>
+static int launch256px(GemmArgs a, hipStream_t s) { return launch256p<EPI, 4, true>(a, s); }
 
 // 0 auto, 1 force 128x128, 2 force 256x256 (one tile per workgroup), 3 force persistent 256x256,
-// 4 force persistent 256x128, 5 force persistent 192x256
+// 4 force persistent 256x128, 5 force persistent 192x256 (3-stage weight ring), 6 force persistent 192x256 with the
+// 3-stage ring on the activations, 7 force persistent 256x256 with a 3-stage activation ring (160 KiB of LDS)
 static int g_gemm_variant = 0;
 static int g_gemm_wide = 1;
 extern "C" int coda_gemm_wide_stores(int on) {
@@ -767,7 +786,7 @@ extern "C" int coda_gemm_wide_stores(int on) {
     return CODA_OK;
 }
 extern "C" int coda_gemm_select(int variant) {
-    if (variant < 0 || variant > 5) return CODA_ERR_ARG;
+    if (variant < 0 || variant > 7) return CODA_ERR_ARG;
     g_gemm_variant = variant;
     return CODA_OK;
 }
@@ -786,7 +805,9 @@ static int pick_engine(const GemmArgs& a) {
     const long t128 = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
     const long t192 = (long)((a.M + 191) / 192) * ((a.N + 255) / 256);
     if (a.N >= 256 && t256 >= 200 && fill(t256) >= 0.85) return 3;
-    if (a.N >= 256 && t192 >= 200 && fill(t192) >= 0.85) return 5;    // e.g. 12288 x 2048: 512 tiles = 2 full rounds
+    // e.g. 12288 x 2048: 512 tiles = 2 full rounds.  The third ring stage goes to the activations: in the decoder
+    // they are what the previous kernel just wrote (down_proj: 151 MB, beyond every cache), -4..5 % with cold operands
+    if (a.N >= 256 && t192 >= 200 && fill(t192) >= 0.85) return 6;
     if (a.m_count) return a.N >= 256 && t256 >= 200 ? 3 : 0;     // counted launches: engines that read m_count
     if (t128 >= 200 && fill(t128) >= 0.85) return 4;
     return 0;
@@ -834,6 +855,8 @@ extern "C" int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, c
         case EPI_F32: return fn<EPI_F32>(a, s);                \
         default: return CODA_ERR_ARG;                          \
     }
+    if (engine == 7) { CODA_DISPATCH(launch256px) }
+    if (engine == 6) { CODA_DISPATCH(launch192x256px) }
     if (engine == 5) { CODA_DISPATCH(launch192x256p) }
     if (engine == 4) { CODA_DISPATCH(launch256x128p) }
     if (engine == 3) { CODA_DISPATCH(launch256p) }
@@ -865,6 +888,7 @@ extern "C" int coda_gemm_bf16_counted(const void* X, long long ldx, const int* m
     a.tiles_m = (M_max + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
     a.wide = g_gemm_wide && (((uintptr_t)C | (uintptr_t)(ldc * 2)) & 15) == 0;
     const int engine = pick_engine(a);
+    if (engine == 6) return launch192x256px<EPI_PLAIN>(a, (hipStream_t)stream);
     if (engine == 5) return launch192x256p<EPI_PLAIN>(a, (hipStream_t)stream);
     if (engine == 3) return launch256p<EPI_PLAIN>(a, (hipStream_t)stream);
     return launch<EPI_PLAIN>(a, (hipStream_t)stream);
