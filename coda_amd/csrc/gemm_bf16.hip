@@ -488,7 +488,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
     auto dma_x = [&](char* dst) -> bool {
         if (xL >= ntiles) return false;
         {
+#ifdef CODA_DIAG_HOTK                            // diagnostic builds only: every K tile re-reads K tile 0 (cache-hot operands)
+            const size_t kb = 0;
+#else
             const size_t kb = (size_t)xk * T::BK * 2;
+#endif
 #pragma unroll
             for (int i = 0; i < T::X_DMA; ++i) glds16(a.X + kb + xoff[i], dst + (i * 8 + wave) * 1024);
             if (++xk == nk) {
@@ -505,7 +509,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
     };
     auto dma_w = [&](char* dst) -> bool {
         if (wL >= ntiles) return false;
+#ifdef CODA_DIAG_HOTK
+        const size_t kb = 0;
+#else
         const size_t kb = (size_t)wk * T::BK * 2;
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16(a.W + kb + woff[i], dst + (i * 8 + wave) * 1024);
         if (++wk == nk) {
@@ -532,13 +540,36 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
     typename T::Frags f;
     T::template load_w<0, 0>(f, ws, p0);
     T::template load_x<0, 0>(f, xs, p0);
+#ifdef CODA_CLOCK_PROBE
+    // diagnostic build only (tools/clock_probe.sh): in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz around
+    // the workgroup's whole tile stream; the stamps go to a buffer of their own (passed as R of a SwiGLU launch)
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // stores one wave issues per full tile: 8-byte pieces, or 16-byte pieces on the widened path (epilogue_wave)
     constexpr int ST_NARROW = (EPI == EPI_SWIGLU ? 2 : 4) * T::MT;
     constexpr int ST_WIDE = EPI == EPI_F32 ? ST_NARROW : ST_NARROW / 2;
+    bool young = false;                       // 3-stage ring: a DMA younger than what the next sync needs is in flight
+    auto issue_dma = [&](int xdst, int wdst) {
+#ifdef CODA_DIAG_NO_DMA
+        return;
+#endif
+        if constexpr (XST == 3) {
+            dma_w(lds + XR + wdst);
+            young = dma_x(lds + xdst);
+        } else {
+            dma_x(lds + xdst);
+            young = dma_w(lds + XR + wdst);
+        }
+    };
+#ifndef CODA_DMA_LATE_HALF
+#define CODA_DMA_LATE_HALF(w) ((w) >> 2)
+#endif
+    const bool late = CODA_DMA_LATE_HALF(wave) & 1;
+    bool pend = false;
+    int pend_x = 0, pend_w = 0;
     int xcur = 0, wcur = 0;                   // byte offsets of the ring stages holding the current K tile
     int stores_in_flight = 0;                 // stores of the previous tile's epilogue if it was the unconditional (full-tile) one
-    bool young = false;                       // 3-stage ring: a DMA younger than what the next sync needs is in flight
     for (; Lc < ntiles; Lc += G) {
         coords(Lc, cm0, cn0);
         f32x4_t acc[4][T::MT];
@@ -553,6 +584,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
             const char* wc = ws + wcur;
             tile256::phase_begin(); T::template load_w<1, 1>(f, wc, p0); T::template quad<0, 0, 0, 0>(f, acc);
             tile256::phase_begin(); T::template load_x<1, 1>(f, xc, p0); T::template quad<1, 0, 1, 0>(f, acc);
+            if (pend) {                           // late half: the DMA of the previous K tile's sync (see below)
+                issue_dma(pend_x, pend_w);
+                pend = false;
+            }
             tile256::phase_begin(); T::template load_x<0, 0>(f, xc, p1); T::template quad<1, 1, 1, 1>(f, acc);
             tile256::phase_begin(); T::template load_w<1, 1>(f, wc, p1); T::template quad<0, 1, 0, 1>(f, acc);
             tile256::phase_begin(); T::template load_w<0, 0>(f, wc, p1); T::template quad<1, 0, 1, 0>(f, acc);
@@ -561,6 +596,15 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
             // landed.  vmcnt retires in order, so what may stay in flight is exactly what was issued AFTER
             // the next tile's DMA: the deeper ring's tile one further ahead (YOUNG instructions, issued LAST in its
             // iteration) and the previous output tile's epilogue stores.
+#ifdef CODA_DIAG_NO_SYNC                         // diagnostic builds only: no K-tile wait / barrier (wrong results)
+            if (false)
+#endif
+#ifdef CODA_DIAG_NO_VMCNT                        // diagnostic builds only: barrier without waiting for the DMA
+            if (true) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            } else
+#endif
             {
                 const int st = t == 0 ? stores_in_flight : 0;
                 if (YOUNG && young) {
@@ -572,21 +616,34 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
                     else if (st == ST_WIDE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ST_WIDE) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 }
+#ifndef CODA_DIAG_NO_BARRIER
                 __builtin_amdgcn_s_barrier();
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (XST == 3) {
-                dma_w(lds + XR + wcur);
-                young = dma_x(lds + xcur);
-            } else {
-                dma_x(lds + xcur);
-                young = dma_w(lds + XR + wcur);
-            }
+            // The CU's address path takes one 1-KiB LDS-DMA piece per ~16 cycles, and a wave cannot issue its next MFMA
+            // until its own pieces are accepted: eight waves issuing their eight pieces together after the barrier
+            // leave the MFMA pipe idle for ~600 cycles per K tile (tools/clock_probe.py: 3000 cycles per K tile with
+            // the DMA, 2400 without, whether or not anybody waits for the data).  So the two waves that share a SIMD
+            // issue at different times: one right after the barrier while its partner multiplies alone, the partner two
+            // phases into the next K tile (after phase 7 when an epilogue follows) while the first one catches up:
+            // 901k -> 779k cycles per workgroup on the gate|up shape; the chip gives about half of it back as a lower
+            // clock (2.01 -> 1.86 GHz), -6 % wall.
+            if (!late) issue_dma(xcur, wcur);
             T::template load_x<0, 0>(f, xs + xnxt, p0);      // first fragments of the next K tile (stale bytes after the last one: unused)
             T::template quad<0, 1, 0, 1>(f, acc);
             tile256::phase_begin();
             T::template load_w<0, 0>(f, ws + wnxt, p0);
             T::template quad<1, 1, 1, 1>(f, acc);
+            if (late) {
+                if (t + 1 < nk) {                 // ... two phases into the next K tile, clear of the first half's burst
+                    pend = true;
+                    pend_x = xcur;
+                    pend_w = wcur;
+                } else {                          // before an epilogue: keeps [DMA][epilogue stores] in issue order
+                    issue_dma(xcur, wcur);
+                }
+            }
             xcur = xnxt;
             wcur = wnxt;
         }
@@ -595,6 +652,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
         else epilogue_tile<EPI, T::MT>(a, acc, cm0 + wm * (T::BM / 2), cn0 + wn * 64, lane, full);
         stores_in_flight = full ? (a.wide && EPI != EPI_F32 ? ST_WIDE : ST_NARROW) : 0;
     }
+#ifdef CODA_CLOCK_PROBE
+    if (EPI == EPI_SWIGLU && a.R && threadIdx.x == 0) {
+        unsigned long long* out = (unsigned long long*)a.R + 2 * blockIdx.x;
+        out[0] = __builtin_amdgcn_s_memtime() - probe_t0;
+        out[1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
+    }
+#endif
 }
 
 template <int EPI, int MTH = 4, bool XDEEP = false>

@@ -30,7 +30,9 @@ __device__ __forceinline__ int dma_chunk(int lane) { return (lane & 7) ^ (lane >
 // Retire the LDS reads issued during the previous phase BEFORE this phase issues its own, so the new
 // reads stay in flight under this phase's MFMAs (hipcc would otherwise wait lgkmcnt(0) after them).
 __device__ __forceinline__ void phase_begin() {
+#ifndef CODA_DIAG_NO_LGKM                        // diagnostic builds only (tools/clock_probe.sh): wrong results, cycle accounting
     __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0) only
+#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 
