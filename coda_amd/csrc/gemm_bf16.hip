@@ -582,14 +582,23 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
             const int wnxt = wcur == (WST - 1) * T::W_BYTES ? 0 : wcur + T::W_BYTES;
             const char* xc = xs + xcur;
             const char* wc = ws + wcur;
+#ifndef CODA_DMA_LATE_SLOT
+#define CODA_DMA_LATE_SLOT 1                     // the late half issues after phase 1 of the next K tile (A/B: 0..3)
+#endif
+            auto late_dma = [&]() {               // late half: the DMA of the previous K tile's sync (see below)
+                if (pend) {
+                    issue_dma(pend_x, pend_w);
+                    pend = false;
+                }
+            };
             tile256::phase_begin(); T::template load_w<1, 1>(f, wc, p0); T::template quad<0, 0, 0, 0>(f, acc);
+            if (CODA_DMA_LATE_SLOT == 0) late_dma();
             tile256::phase_begin(); T::template load_x<1, 1>(f, xc, p0); T::template quad<1, 0, 1, 0>(f, acc);
-            if (pend) {                           // late half: the DMA of the previous K tile's sync (see below)
-                issue_dma(pend_x, pend_w);
-                pend = false;
-            }
+            if (CODA_DMA_LATE_SLOT == 1) late_dma();
             tile256::phase_begin(); T::template load_x<0, 0>(f, xc, p1); T::template quad<1, 1, 1, 1>(f, acc);
+            if (CODA_DMA_LATE_SLOT == 2) late_dma();
             tile256::phase_begin(); T::template load_w<1, 1>(f, wc, p1); T::template quad<0, 1, 0, 1>(f, acc);
+            if (CODA_DMA_LATE_SLOT == 3) late_dma();
             tile256::phase_begin(); T::template load_w<0, 0>(f, wc, p1); T::template quad<1, 0, 1, 0>(f, acc);
             tile256::phase_begin(); T::template load_x<1, 1>(f, xc, p1); T::template quad<0, 0, 0, 0>(f, acc);
             // Every wave has retired its reads of these stages, and the next K tile of the stream must have

@@ -20,6 +20,7 @@ for tag, (label, fill) in [(t, f) for t in tags for f in fills]:
     lib = ctypes.CDLL(os.path.join(ROOT, "tools", "probe", f"libcoda_hip_probe_{tag}.so"))
     lib.coda_gemm_bf16.argtypes = [P, LL, P, P, LL, P, LL, P, LL, I, I, I, I, P]
     lib.coda_gemm_bf16.restype = I
+    lib.coda_gemm_select(int(os.environ.get("GEMM_VARIANT", "0")))
     label = f"{tag:10s} {label}"
     X = (torch.randn(M, K, device=DEV) if fill == "randn" else torch.zeros(M, K, device=DEV)).to(BF)
     W = ((torch.randn(N, K, device=DEV) * 0.02) if fill == "randn" else torch.zeros(N, K, device=DEV)).to(BF)
