@@ -19,6 +19,9 @@ struct GemmArgs {
     int M, N, K;
     int tiles_m, tiles_n;
     int wide;                       // C (and R) rows are 16-byte aligned: interior tiles may use 16-byte stores / residual loads
+#ifdef CODA_CLOCK_PROBE
+    unsigned long long* probe;      // diagnostic build only: per-workgroup (d s_memtime, d s_memrealtime)
+#endif
     // EPI_QKROPE only: q/k RMSNorm weights, rotary tables [L,128], sequence length, feature bounds of q and q|k
     const char* qn_w; const char* kn_w; const char* rope_cos; const char* rope_sin;
     int L, q_feat, qk_feat; float eps;
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
     T::template load_x<0, 0>(f, xs, p0);
 #ifdef CODA_CLOCK_PROBE
     // diagnostic build only (tools/clock_probe.sh): in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz around
-    // the workgroup's whole tile stream; the stamps go to a buffer of their own (passed as R of a SwiGLU launch)
+    // the workgroup's whole tile stream; the stamps go to a buffer of their own (coda_gemm_probe)
     const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
@@ -657,13 +660,22 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
             wcur = wnxt;
         }
         const bool full = cm0 + T::BM <= a.M && cn0 + T::BN <= a.N;
-        if constexpr (EPI == EPI_QKROPE) epilogue256_qkrope(a, acc, cm0, cn0, wm, wn, wave, lane, (float*)(lds + PL::BYTES), full);
-        else epilogue_tile<EPI, T::MT>(a, acc, cm0 + wm * (T::BM / 2), cn0 + wn * 64, lane, full);
+#ifdef CODA_DIAG_NO_EPI                          // diagnostic builds only: the epilogue never runs (the test keeps the accumulators alive)
+        if (__builtin_amdgcn_readfirstlane(__float_as_int(acc[0][0][0])) == 0x12345678) {
+#else
+        {
+#endif
+            if constexpr (EPI == EPI_QKROPE) epilogue256_qkrope(a, acc, cm0, cn0, wm, wn, wave, lane, (float*)(lds + PL::BYTES), full);
+            else epilogue_tile<EPI, T::MT>(a, acc, cm0 + wm * (T::BM / 2), cn0 + wn * 64, lane, full);
+        }
         stores_in_flight = full ? (a.wide && EPI != EPI_F32 ? ST_WIDE : ST_NARROW) : 0;
+#ifdef CODA_DIAG_NO_EPI
+        stores_in_flight = 0;
+#endif
     }
 #ifdef CODA_CLOCK_PROBE
-    if (EPI == EPI_SWIGLU && a.R && threadIdx.x == 0) {
-        unsigned long long* out = (unsigned long long*)a.R + 2 * blockIdx.x;
+    if (a.probe && threadIdx.x == 0) {
+        unsigned long long* out = a.probe + 2 * blockIdx.x;
         out[0] = __builtin_amdgcn_s_memtime() - probe_t0;
         out[1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
     }
@@ -854,6 +866,13 @@ static int launch256px(GemmArgs a, hipStream_t s) { return launch256p<EPI, 4, tr
 // 3-stage ring on the activations, 7 force persistent 256x256 with a 3-stage activation ring (160 KiB of LDS)
 static int g_gemm_variant = 0;
 static int g_gemm_wide = 1;
+#ifdef CODA_CLOCK_PROBE
+static unsigned long long* g_gemm_probe = nullptr;
+extern "C" int coda_gemm_probe(void* buf) {
+    g_gemm_probe = (unsigned long long*)buf;
+    return CODA_OK;
+}
+#endif
 extern "C" int coda_gemm_wide_stores(int on) {
     g_gemm_wide = on ? 1 : 0;
     return CODA_OK;
@@ -918,6 +937,9 @@ extern "C" int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, c
     a.M = M; a.N = N; a.K = K;
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
     a.wide = g_gemm_wide && (((uintptr_t)C | (uintptr_t)(ldc * esz)) & 15) == 0 && (!R || (((uintptr_t)R | (uintptr_t)(ldr * 2)) & 15) == 0);
+#ifdef CODA_CLOCK_PROBE
+    a.probe = g_gemm_probe;
+#endif
     hipStream_t s = (hipStream_t)stream;
     const int engine = pick_engine(a);
 #define CODA_DISPATCH(fn)                                      \

@@ -86,14 +86,18 @@ struct Tile {
     // 2*MTH MFMAs: one quadrant (2 nt x MTH mt) of the wave's tile for one 32-deep k-step
     template <int WSET, int XSET, int NH, int MH>
     static __device__ __forceinline__ void quad(const Frags& f, f32x4_t (&acc)[4][MT]) {
+#ifndef CODA_DIAG_NO_SETPRIO
         __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int i = 0; i < MTH; ++i)
                 acc[NH * 2 + j][MH * MTH + i] =
                     __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[WSET][j], f.x[XSET][i], acc[NH * 2 + j][MH * MTH + i], 0, 0, 0);
+#ifndef CODA_DIAG_NO_SETPRIO
         __builtin_amdgcn_s_setprio(0);
+#endif
     }
 
     // acc[nt][mt]; wave (wm = wave>>2: token half, wn = wave&3: feature quarter).
