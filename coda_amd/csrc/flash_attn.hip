@@ -35,6 +35,9 @@ struct AttnArgs {
     int B, L, n_q, n_kv;
     int qsplit;                  // workgroups per (batch, head): block qs handles query blocks qs, qs + qsplit, ...
     float scale_log2e;
+#ifdef CODA_CLOCK_PROBE
+    unsigned long long* probe;   // diagnostic build only: per-workgroup (d s_memtime, d s_memrealtime)
+#endif
 };
 
 __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -223,6 +226,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnArgs a) {
         lgkm0(); pv(3, vB);
     };
 
+#ifdef CODA_CLOCK_PROBE
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int nt = (L + KB - 1) / KB;
     const int n_full = L / KB;                     // tiles without a ragged edge
     int gt = 0;                                    // tiles consumed so far: the ring position
@@ -277,9 +283,23 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnArgs a) {
                 if (q_row < L) *(u32x4_t*)(op + d * 2) = v;
             }
     }
+#ifdef CODA_CLOCK_PROBE
+    if (a.probe && threadIdx.x == 0) {
+        a.probe[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - probe_t0;
+        a.probe[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
+    }
+#endif
 }
 
 }  // namespace
+
+#ifdef CODA_CLOCK_PROBE
+static unsigned long long* g_attn_probe = nullptr;
+extern "C" int coda_attn_probe(void* buf) {
+    g_attn_probe = (unsigned long long*)buf;
+    return CODA_OK;
+}
+#endif
 
 extern "C" int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void* out, long long ld_out, int B, int L,
                                          int n_q, int n_kv, float scale, void* stream) {
@@ -322,6 +342,9 @@ extern "C" int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void
         const int v = atoi(e);
         if (v > 0) a.qsplit = v < nqb ? v : nqb;
     }
+#ifdef CODA_CLOCK_PROBE
+    a.probe = g_attn_probe;
+#endif
     hipLaunchKernelGGL(flash_attn_kernel, dim3(a.qsplit * n_q * B), dim3(256), ATTN_LDS, (hipStream_t)stream, a);
     CODA_CHECK_LAUNCH("flash_attn");
     return CODA_OK;
