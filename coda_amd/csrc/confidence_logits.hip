@@ -46,20 +46,24 @@ __device__ __forceinline__ int iadd_op(int a, int b) { return a + b; }
 __device__ __forceinline__ int imin_op(int a, int b) { return min(a, b); }
 
 __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
-    __shared__ float hist_f[256];
-    __shared__ int hist_i[256];
+    // Radix histograms: NSUB private copies, one per group of 64 / NSUB lanes.  bf16 logits share a handful of
+    // sign|exponent bytes, so on one copy nearly all 64 lanes of an LDS atomic hit the same bin and serialise.
+    constexpr int NSUB = 4;
+    __shared__ unsigned long long hist_m[NSUB * 256];
+    __shared__ int hist_i[NSUB * 256];
     __shared__ float red_f[4];
     __shared__ int red_i[4];
     __shared__ unsigned int sh_prefix;
-    __shared__ float sh_acc;
+    __shared__ unsigned long long sh_acc, sh_lim, sh_tie_mass;
+    __shared__ int sh_seg[256];
     __shared__ int sh_k;
-    __shared__ int sh_wave_tot[4];
-    __shared__ int sh_base, sh_cut;
+    __shared__ int sh_cut;
 
     const int row = blockIdx.x;
     const int n_rows = a.count ? min(a.count[0], a.N) : a.N;
     if (row >= n_rows) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int sub = (lane & (NSUB - 1)) * 256;        // this lane's histogram copy
     const int V = a.V;
     const bool sampled = a.temperature > 0.f;
     const char* rp = a.logits + (size_t)row * a.ld_b;
@@ -76,10 +80,55 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
         return x;
     };
     const int kbits = a.is_bf16 ? 16 : 32;   // significant key bits (bf16 values have zero low halves)
+    // Every pass streams the row through fn(v, x).  16-byte loads (8 bf16 / 4 fp32 per lane) when the row is 16-byte
+    // aligned: with 2-byte loads the passes were bound by the NUMBER of load instructions (one per element and lane),
+    // 8x more than needed.  Reductions below do not depend on the order in which a thread meets its elements.
+    const bool vec_ok = (((uintptr_t)rp) & 15) == 0;
+    const int per = a.is_bf16 ? 8 : 4;
+    const int nvec = vec_ok ? V / per : 0;
+    auto xform = [&](float x) -> float {
+        if (!sampled) return x;
+        x = __fdiv_rn(x, a.temperature);
+        return a.is_bf16 ? round_bf16(x) : x;
+    };
+    auto for_each = [&](auto&& fn) {
+        if (a.is_bf16) {
+            // four loads in flight per lane: one 16-byte load per iteration leaves ~25 KB in flight per CU, well under
+            // what HBM latency x bandwidth asks for
+            int cidx = tid;
+            for (; cidx + 3 * 256 < nvec; cidx += 4 * 256) {
+                u32x4_t raw[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) raw[u] = *(const u32x4_t*)(rp + (size_t)(cidx + u * 256) * 16);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        fn((cidx + u * 256) * 8 + 2 * j, xform(bf16_lo(raw[u][j])));
+                        fn((cidx + u * 256) * 8 + 2 * j + 1, xform(bf16_hi(raw[u][j])));
+                    }
+            }
+            for (; cidx < nvec; cidx += 256) {
+                const u32x4_t raw = *(const u32x4_t*)(rp + (size_t)cidx * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    fn(cidx * 8 + 2 * j, xform(bf16_lo(raw[j])));
+                    fn(cidx * 8 + 2 * j + 1, xform(bf16_hi(raw[j])));
+                }
+            }
+        } else {
+            for (int cidx = tid; cidx < nvec; cidx += 256) {
+                const f32x4_t raw = *(const f32x4_t*)(rp + (size_t)cidx * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fn(cidx * 4 + j, xform(raw[j]));
+            }
+        }
+        for (int v = nvec * per + tid; v < V; v += 256) fn(v, logit(v));
+    };
 
     // ---- softmax statistics of the unfiltered row (needed by top-p)
     float mx = -INFINITY;
-    for (int v = tid; v < V; v += 256) mx = fmaxf(mx, logit(v));
+    for_each([&](int, float x) { mx = fmaxf(mx, x); });
     mx = block_reduce<float>(mx, red_f, tid, fmax_op);
 
     const bool use_p = a.top_p > 0.f && a.top_p < 1.f;
@@ -89,79 +138,120 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
     unsigned int kk = 0u;        // top-k threshold key (keep key >= kk)
 
     if (use_p) {
-        float z = 0.f;
-        for (int v = tid; v < V; v += 256) z += __expf(logit(v) - mx);
-        z = block_reduce<float>(z, red_f, tid, fadd_op);
-        const float inv_z = 1.0f / z;
+        // Probability mass is accumulated in 64-bit FIXED POINT (e^(x - max) * 2^40, integer LDS atomics): float LDS
+        // atomics on the few hot bins were 70 % of this kernel's time, integer ones are an order cheaper, exact and
+        // order-independent (the float histogram rounded differently from run to run).  152k entries of at most 2^40
+        // sum below 2^58; one entry is resolved to 2^-40 of the row maximum's mass.  The first radix pass sees every
+        // entry, so its bins also give the normaliser: thresholds are compared against top_p * (total mass).
+        constexpr float FIX = 1099511627776.0f;               // 2^40
+        auto mass = [&](float x) -> unsigned long long { return (unsigned long long)(__expf(x - mx) * FIX); };
         // radix select: smallest key K whose strictly-above probability mass A(K) <= top_p
         unsigned int prefix = 0u;
-        float acc = 0.f;             // mass of keys above the current prefix range
+        unsigned long long acc = 0ull;   // mass of keys above the current prefix range
+        unsigned long long lim = 0ull;   // top_p * total mass
         for (int shift = 24; shift >= 32 - kbits; shift -= 8) {
-            hist_f[tid] = 0.f;
-            hist_i[tid] = 0;
+#pragma unroll
+            for (int c = 0; c < NSUB; ++c) {
+                hist_m[c * 256 + tid] = 0ull;
+                hist_i[c * 256 + tid] = 0;
+            }
             __syncthreads();
             const unsigned int hi_mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
-            for (int v = tid; v < V; v += 256) {
-                const float x = logit(v);
+            for_each([&](int, float x) {
                 const unsigned int k = fkey(x);
                 if ((k & hi_mask) == prefix) {
-                    atomicAdd(&hist_f[(k >> shift) & 255], __expf(x - mx) * inv_z);
-                    atomicAdd(&hist_i[(k >> shift) & 255], 1);
+                    atomicAdd(&hist_m[sub + ((k >> shift) & 255)], mass(x));
+                    atomicAdd(&hist_i[sub + ((k >> shift) & 255)], 1);
                 }
+            });
+            __syncthreads();
+            {
+                unsigned long long hm = 0ull;
+                int hi = 0;
+#pragma unroll
+                for (int c = 0; c < NSUB; ++c) {
+                    hm += hist_m[c * 256 + tid];
+                    hi += hist_i[c * 256 + tid];
+                }
+                __syncthreads();
+                hist_m[tid] = hm;
+                hist_i[tid] = hi;
             }
             __syncthreads();
             if (tid == 0) {
-                float run = acc;
+                if (shift == 24) {
+                    unsigned long long tot = 0ull;
+                    for (int bin = 0; bin < 256; ++bin) tot += hist_m[bin];
+                    sh_lim = (unsigned long long)((double)a.top_p * (double)tot);
+                }
+                const unsigned long long lm = sh_lim;
+                unsigned long long run = acc, pick_acc = acc;
                 int pick = -1;
-                float pick_acc = acc;
                 for (int bin = 255; bin >= 0; --bin) {
                     if (hist_i[bin] == 0) continue;
-                    if (run <= a.top_p || pick < 0) { pick = bin; pick_acc = run; }   // pick < 0: the top key is always kept
+                    if (run <= lm || pick < 0) { pick = bin; pick_acc = run; }   // pick < 0: the top key is always kept
                     else break;
-                    run += hist_f[bin];
+                    run += hist_m[bin];
                 }
                 sh_prefix = prefix | ((unsigned int)pick << shift);
                 sh_acc = pick_acc;
+                sh_k = hist_i[pick];                 // at the last level: the entries equal to the threshold key ...
+                sh_tie_mass = hist_m[pick];          // ... and their total mass
             }
             __syncthreads();
             prefix = sh_prefix;
             acc = sh_acc;
+            lim = sh_lim;
             __syncthreads();
         }
         kp = prefix;
         // ties at the threshold: the reference keeps them one by one while the running mass <= top_p
-        int ties = 0;
-        float pt = 0.f;
-        for (int v = tid; v < V; v += 256) {
-            const float x = logit(v);
-            if (fkey(x) == kp) { ++ties; pt = __expf(x - mx) * inv_z; }
-        }
-        ties = block_reduce<int>(ties, red_i, tid, iadd_op);
-        pt = block_reduce<float>(pt, red_f, tid, fmax_op);
+        const int ties = sh_k;
+        const unsigned long long pt = ties > 0 ? sh_tie_mass / (unsigned long long)ties : 0ull;   // equal keys: equal masses
         int keep_ties = ties;
-        if (pt > 0.f) {
-            const float room = (a.top_p - acc) / pt;
-            if (room < (float)ties) keep_ties = max(1, min(ties, (int)floorf(room) + 1));
+        if (pt > 0ull && lim >= acc) {
+            const unsigned long long room = (lim - acc) / pt;
+            if (room < (unsigned long long)ties) keep_ties = max(1, min(ties, (int)room + 1));
+        } else if (pt > 0ull) {
+            keep_ties = 1;
         }
         if (keep_ties < ties) {
-            // index of the keep_ties-th tie in index order (ordered scan)
-            if (tid == 0) { sh_base = 0; sh_cut = 0x7fffffff; }
+            // index of the keep_ties-th tie in index order: every thread counts the ties of its own contiguous segment,
+            // a scan over the 256 counts finds the segment that holds it, and that thread walks its segment again
+            const int seg = ((V + 255) / 256 + 7) & ~7;        // multiple of 8: 16-byte aligned segments of bf16
+            const int v0 = min(V, tid * seg), v1 = min(V, v0 + seg);
+            const bool seg_vec = vec_ok && a.is_bf16 && (V & 7) == 0;
+            // walk(fn): fn(v, is_tie) over the segment in index order; fn returns true to stop
+            auto walk = [&](auto&& fn) {
+                if (seg_vec) {
+                    for (int v = v0; v < v1; v += 8) {
+                        const u32x4_t raw = *(const u32x4_t*)(rp + (size_t)v * 2);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (fn(v + 2 * j, fkey(xform(bf16_lo(raw[j]))) == kp)) return;
+                            if (fn(v + 2 * j + 1, fkey(xform(bf16_hi(raw[j]))) == kp)) return;
+                        }
+                    }
+                } else {
+                    for (int v = v0; v < v1; ++v)
+                        if (fn(v, fkey(logit(v)) == kp)) return;
+                }
+            };
+            int mine = 0;
+            walk([&](int, bool tie) { mine += tie ? 1 : 0; return false; });
+            sh_seg[tid] = mine;
+            if (tid == 0) sh_cut = 0x7fffffff;
             __syncthreads();
-            for (int start = 0; start < V; start += 256) {
-                const int v = start + tid;
-                const bool flag = v < V && fkey(logit(v)) == kp;
-                const unsigned long long bal = __ballot(flag);
-                const int pre = __popcll(bal & ((1ull << lane) - 1ull));
-                if (lane == 0) sh_wave_tot[wave] = __popcll(bal);
-                __syncthreads();
-                int off = sh_base;
-                for (int w = 0; w < wave; ++w) off += sh_wave_tot[w];
-                if (flag && off + pre + 1 == keep_ties) sh_cut = v;
-                __syncthreads();
-                if (tid == 0) sh_base += sh_wave_tot[0] + sh_wave_tot[1] + sh_wave_tot[2] + sh_wave_tot[3];
-                __syncthreads();
-                if (sh_base >= keep_ties) break;
+            int before = 0;
+            for (int w = 0; w < tid; ++w) before += sh_seg[w];
+            if (before < keep_ties && before + mine >= keep_ties) {
+                int need = keep_ties - before;
+                walk([&](int v, bool tie) {
+                    if (tie && --need == 0) { sh_cut = v; return true; }
+                    return false;
+                });
             }
+            __syncthreads();
             p_cut = sh_cut;
         }
     }
@@ -171,12 +261,21 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
         unsigned int prefix = 0u;
         int want = a.top_k;
         for (int shift = 24; shift >= 32 - kbits; shift -= 8) {
-            hist_i[tid] = 0;
+#pragma unroll
+            for (int c = 0; c < NSUB; ++c) hist_i[c * 256 + tid] = 0;
             __syncthreads();
             const unsigned int hi_mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
-            for (int v = tid; v < V; v += 256) {
-                const unsigned int k = fkey(logit(v));
-                if ((k & hi_mask) == prefix) atomicAdd(&hist_i[(k >> shift) & 255], 1);
+            for_each([&](int, float x) {
+                const unsigned int k = fkey(x);
+                if ((k & hi_mask) == prefix) atomicAdd(&hist_i[sub + ((k >> shift) & 255)], 1);
+            });
+            __syncthreads();
+            {
+                int hi = 0;
+#pragma unroll
+                for (int c = 0; c < NSUB; ++c) hi += hist_i[c * 256 + tid];
+                __syncthreads();
+                hist_i[tid] = hi;
             }
             __syncthreads();
             if (tid == 0) {
@@ -212,9 +311,8 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
     float bkey = -INFINITY, bl = 0.f;
     int barg = 0x7fffffff;
     const unsigned int rowkey = a.dst_pos ? (unsigned int)a.dst_pos[row] : (unsigned int)row;
-    for (int v = tid; v < V; v += 256) {
-        const float x = logit(v);
-        if (!kept(v, fkey(x))) continue;
+    for_each([&](int v, float x) {
+        if (!kept(v, fkey(x))) return;
         const float d = x - mx, e = __expf(d);
         z += e;
         s += e * d;
@@ -225,7 +323,7 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
             const float key = x - __logf(q);
             if (key > bkey || (key == bkey && v < barg)) { bkey = key; bl = x; barg = v; }
         }
-    }
+    });
     z = block_reduce<float>(z, red_f, tid, fadd_op);
     s = block_reduce<float>(s, red_f, tid, fadd_op);
     m2 = block_reduce<float>(m2, red_f, tid, fmax_op);
