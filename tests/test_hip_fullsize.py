@@ -119,3 +119,38 @@ def test_c2_teacher_forced_sample_vs_cpu_oracle(full):
           f"{len(stats['violations'])} violations")
     assert stats["candidates"] > 100
     assert not stats["violations"], stats["violations"][:5]
+
+
+@pytest.mark.parametrize("name,cfg,block", [
+    ("C4-like", dict(alg="maskgit_plus", temperature=0.7, top_p=0.9), 16),
+    ("C5-like", dict(alg="topk_margin", alg_temp=0.1), None),
+    ("E1-like", dict(alg="entropy", temperature=0.1, top_p=0.9, alg_temp=0.0), None),
+    ("serving defaults", dict(alg="entropy", alg_temp=0.1), None),
+])
+def test_full_architecture_stochastic_configs_teacher_forced(full, name, cfg, block):
+    """The other BASELINE.json configurations' sampler settings (C4: T = 0.7 + top-p 0.9 + maskgit_plus + windows,
+    C5: topk_margin + alg_temp 0.1, the lm-eval scripts' T = 0.1 + top-p, the serving defaults) on the full
+    architecture (28 layers, V = 151 936) at a shape the CPU oracle finishes in seconds: the oracle's noise is
+    replayed into the HIP kernels and every step is compared teacher-forced."""
+    from parity import teacher_forced
+    from test_hip_e2e import Replay
+    cfg_m, m, _, _, _, _ = full
+    d = ref_cpu.Dims()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(99)
+    ids = torch.randint(0, 151643, (2, 24), generator=g)
+    kw = dict(max_new_tokens=32, steps=8, block_length=block, **cfg)
+    torch.manual_seed(321)
+    noise = ref_cpu.TorchNoise()
+    ref = ref_cpu.diffusion_generate(sd, d, ids, noise=noise, **kw)
+    trace = []
+    out = m.diffusion_generate(ids.to(DEV), mask_token_id=cfg_m.mask_token_id, noise_source=Replay(noise.log, d.vocab),
+                               return_dict_in_generate=True, output_history=True, debug_trace=trace, **kw)
+    hist = [h.cpu() for h in out.history]
+    stats, tr = teacher_forced(sd, d, ids, hist, trace, noise_log=noise.log, **kw)
+    rate = (out.sequences.cpu() == ref.sequences).float().mean().item()
+    print(f"full architecture, {name}: free-running token match {rate:.3f}; teacher-forced {stats['exact_steps']}/8 steps identical, "
+          f"{stats['band_tok']} tok-band, max conf err {stats['max_conf_err']:.4g} = {stats['max_conf_err_over_tol']:.2f} x tol, "
+          f"{len(stats['violations'])} violations")
+    assert (out.sequences != cfg_m.mask_token_id).all()
+    assert not stats["violations"], stats["violations"][:5]
