@@ -52,6 +52,31 @@ extern "C" int coda_gather_rows(const void* src, long long ld_src, const int* ro
     return CODA_OK;
 }
 
+// inverse of the compaction: dst[rows[i]] = src[i] (the final-normed hidden rows of the last layer's compact tail go
+// back to their token rows, where coda_build_candidates' src_rows point)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const char* __restrict__ src, long long ld_src_b, const int* __restrict__ rows,
+                                                           int n, char* __restrict__ dst, long long ld_dst_b, int dst_rows, int chunks) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int r = rows[i];
+    if (r < 0 || r >= dst_rows) return;
+    const u32x4_t* s = (const u32x4_t*)(src + (size_t)i * ld_src_b);
+    u32x4_t* d = (u32x4_t*)(dst + (size_t)r * ld_dst_b);
+    for (int c = lane; c < chunks; c += 64) d[c] = s[c];
+}
+
+extern "C" int coda_scatter_rows(const void* src, long long ld_src, const int* rows, int n, void* dst, long long ld_dst,
+                                 int dst_rows, int H, void* stream) {
+    if (n <= 0 || dst_rows <= 0 || H <= 0 || H % 8 || ld_src < H || ld_dst < H) return CODA_ERR_SHAPE;
+    if (!src || !rows || !dst) return CODA_ERR_ARG;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) || (ld_src * 2) % 16 || (ld_dst * 2) % 16) return CODA_ERR_ALIGN;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const char*)src, ld_src * 2,
+                       rows, n, (char*)dst, ld_dst * 2, dst_rows, H / 8);
+    CODA_CHECK_LAUNCH("scatter_rows");
+    return CODA_OK;
+}
+
 // ------------------------------------------------------------------ RMSNorm
 // modeling_coda.py:36-41: y = w * bf16(x_f32 * rsqrt(mean(x_f32^2) + eps)), product rounded to bf16.
 __device__ __forceinline__ void unpack8(const u32x4_t v, float (&f)[8]) {

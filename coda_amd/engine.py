@@ -88,6 +88,7 @@ class HipEngine:
         self._shape = None
         self._rope = {}
         self.timer = None          # optional KernelTimer (bench.py)
+        self.prune_last_layer = True   # forward_hidden(need=...): last layer's per-token tail on the consumed rows only
 
     # ------------------------------------------------------------------ workspaces
     def _ensure(self, B: int, L: int):
@@ -132,17 +133,41 @@ class HipEngine:
             t.end(name)
 
     # ------------------------------------------------------------------ decoder forward
+    def _tail_rows(self, B: int, L: int, lo: int, hi: int):
+        """Token rows b*L + [lo, hi) of every sequence, int32 on the device (rebuilt when the range moves: once per block)."""
+        key = (B, L, lo, hi)
+        if getattr(self, "_tail_key", None) != key:
+            dev, bf, R = self.device, torch.bfloat16, B * (hi - lo)
+            self._tail_idx = (torch.arange(B, device=dev, dtype=torch.int32)[:, None] * L
+                              + torch.arange(lo, hi, device=dev, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
+            if getattr(self, "_tail_R", None) != R:
+                self.h_c = torch.empty(R, self.H, device=dev, dtype=bf)
+                self.a_c = torch.empty(R, self.H, device=dev, dtype=bf)
+                self.ao_c = torch.empty(R, self.n_q * self.d, device=dev, dtype=bf)
+                self.mlp_c = torch.empty(R, self.I, device=dev, dtype=bf)
+                self.hn_c = torch.empty(R, self.H, device=dev, dtype=bf)
+                self._tail_R = R
+            self._tail_key = key
+        return self._tail_idx
+
     @torch.no_grad()
-    def forward_hidden(self, ids: torch.Tensor) -> torch.Tensor:
-        """ids int64 [B,L] on the device -> final-normed hidden states bf16 [B*L, H] (engine-owned)."""
+    def forward_hidden(self, ids: torch.Tensor, need=None) -> torch.Tensor:
+        """ids int64 [B,L] on the device -> final-normed hidden states bf16 [B*L, H] (engine-owned).
+
+        ``need=(lo, hi)``: the caller consumes only the rows of positions [lo, hi) of every sequence (the sampler reads
+        the hidden state at p-1 for each candidate position p, generation_utils.py:457,462).  The LAST layer's K/V are
+        still computed for every token, but its per-token tail (o_proj + residual, post-attention norm, MLP + residual,
+        final norm: modeling_coda.py:247-253,353) runs on those rows only, compacted; all other rows of the returned
+        buffer are stale.  Row-wise ops: the needed rows come out as in the full forward."""
         B, L = ids.shape
         self._ensure(B, L)
         T, s = B * L, self._stream()
         cos, sin = self._rope[L]
         ids = ids.contiguous()
+        prune = self.prune_last_layer and need is not None and 0 <= need[0] < need[1] <= L and (need[1] - need[0]) < L
         _lib.call("coda_embed_gather", _ptr(ids), _ptr(self.embed), _ptr(self.h), T, self.V, self.H, s)
         scale = 1.0 / math.sqrt(self.d)
-        for lw in self.lw:
+        for li, lw in enumerate(self.lw):
             _lib.call("coda_rmsnorm", _ptr(self.h), self.H, _ptr(lw["n_in"]), _ptr(self.a), self.H, T, self.H, self.eps, s)
             if self.fuse_qk and T >= 256:
                 t = self.timer
@@ -158,11 +183,27 @@ class HipEngine:
                           _ptr(sin), T, L, self.n_q, self.n_kv, self.eps, s)
             _lib.call("coda_flash_attn_noncausal", _ptr(self.qkv), self.qkv_dim, _ptr(self.ao), self.n_q * self.d, B, L,
                       self.n_q, self.n_kv, scale, s)
+            if prune and li == self.layers - 1:
+                return self._compact_tail(lw, B, L, need[0], need[1])
             self._gemm("o_proj", self.ao, lw["wo"], self.h, _lib.EPI_RESIDUAL, R=self.h)
             _lib.call("coda_rmsnorm", _ptr(self.h), self.H, _ptr(lw["n_post"]), _ptr(self.a), self.H, T, self.H, self.eps, s)
             self._gemm("gate_up", self.a, lw["wgu"], self.mlp, _lib.EPI_SWIGLU)
             self._gemm("down", self.mlp, lw["wd"], self.h, _lib.EPI_RESIDUAL, R=self.h)
         _lib.call("coda_rmsnorm", _ptr(self.h), self.H, _ptr(self.final_norm), _ptr(self.hn), self.H, T, self.H, self.eps, s)
+        return self.hn
+
+    def _compact_tail(self, lw, B: int, L: int, lo: int, hi: int) -> torch.Tensor:
+        """Last layer after attention, on the rows b*L + [lo, hi) only (see forward_hidden)."""
+        rows = self._tail_rows(B, L, lo, hi)
+        R, s, D = rows.numel(), self._stream(), self.n_q * self.d
+        _lib.call("coda_gather_rows", _ptr(self.ao), D, _ptr(rows), None, R, _ptr(self.ao_c), D, D, s)
+        _lib.call("coda_gather_rows", _ptr(self.h), self.H, _ptr(rows), None, R, _ptr(self.h_c), self.H, self.H, s)
+        self._gemm("o_proj_tail", self.ao_c, lw["wo"], self.h_c, _lib.EPI_RESIDUAL, R=self.h_c)
+        _lib.call("coda_rmsnorm", _ptr(self.h_c), self.H, _ptr(lw["n_post"]), _ptr(self.a_c), self.H, R, self.H, self.eps, s)
+        self._gemm("gate_up_tail", self.a_c, lw["wgu"], self.mlp_c, _lib.EPI_SWIGLU)
+        self._gemm("down_tail", self.mlp_c, lw["wd"], self.h_c, _lib.EPI_RESIDUAL, R=self.h_c)
+        _lib.call("coda_rmsnorm", _ptr(self.h_c), self.H, _ptr(self.final_norm), _ptr(self.hn_c), self.H, R, self.H, self.eps, s)
+        _lib.call("coda_scatter_rows", _ptr(self.hn_c), self.H, _ptr(rows), R, _ptr(self.hn), self.H, B * L, self.H, s)
         return self.hn
 
     @torch.no_grad()

@@ -265,7 +265,9 @@ class DLMGenerationMixin:
             cap = B * (hi - lo)
             last = j == steps_b - 1
 
-            hn = eng.forward_hidden(x)
+            # the lm-head reads the hidden state at p-1 for every candidate p in [lo, hi) (:457,462): positions [lo-1, hi-1)
+            s_lo = max(lo - 1, 0)
+            hn = eng.forward_hidden(x, need=None if materialise_all else (s_lo, max(hi - 1, s_lo + 1)))
             eng.build_candidates(x, lo, hi)
             u = picked = None
             if alg == "origin":

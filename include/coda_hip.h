@@ -91,6 +91,13 @@ int coda_gather_rows(const void* src, long long ld_src, const int* rows, const i
 int coda_gemm_bf16_counted(const void* X, long long ldx, const int* m_count, const void* W, long long ldw, void* C,
                            long long ldc, int M_max, int N, int K, void* stream);
 
+/* Inverse of coda_gather_rows: dst[rows[i]] = src[i] for i < n (rows outside [0, dst_rows) are skipped), H bf16 per row.
+ * Used by the last decoder layer's compact tail: only the hidden rows whose logits the sampler consumes
+ * (generation_utils.py:457,462: positions p-1 of the candidate positions p) go through o_proj / the MLP / the final
+ * norm of the LAST layer (modeling_coda.py:247-253,353); their final-normed rows are written back to their token rows. */
+int coda_scatter_rows(const void* src, long long ld_src, const int* rows, int n, void* dst, long long ld_dst,
+                      int dst_rows, int H, void* stream);
+
 /* Non-causal, mask-free GQA flash attention.  Replaces attention.py:12-90 (repeat_kv + SDPA with
  * is_causal=False and no mask).  Reads q/k/v from the fused QKV activation
  * (layout as above), writes out bf16 [T, n_q*128] (token-major, heads concatenated: what o_proj

@@ -121,6 +121,25 @@ def test_golden_free_running(small, golden):
     assert np.mean(rates) > 0.7, rates
 
 
+@pytest.mark.parametrize("block_length", [None, 8])
+def test_last_layer_compact_tail_same_tokens(small, mid, block_length):
+    """engine.forward_hidden(need=...): last layer's o_proj / MLP / norms on the consumed rows only == full forward."""
+    for d, sd, m in (small, mid):
+        g = torch.Generator().manual_seed(9)
+        ids = torch.randint(0, d.pad_id, (5, 40), generator=g).to(DEV)
+        kw = dict(max_new_tokens=32, steps=16, alg="entropy", mask_token_id=d.mask_id, block_length=block_length,
+                  return_dict_in_generate=True, output_history=True)
+        eng = m.hip_engine()
+        a = m.diffusion_generate(ids, **kw)
+        eng.prune_last_layer = False
+        try:
+            b = m.diffusion_generate(ids, **kw)
+        finally:
+            eng.prune_last_layer = True
+        assert torch.equal(a.sequences, b.sequences)
+        assert all(torch.equal(u, v) for u, v in zip(a.history, b.history))
+
+
 def test_fused_equals_materialised_path(small):
     d, sd, m = small
     g = torch.Generator().manual_seed(5)

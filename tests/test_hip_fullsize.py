@@ -87,6 +87,29 @@ def test_c2_deterministic_and_row_independent(full):
     assert rate > 0.9
 
 
+def test_c2_last_layer_compact_tail_equals_full_forward(full):
+    """The last decoder layer's per-token tail runs on the consumed rows only (engine.forward_hidden(need=...)); those
+    rows must equal the full forward's, and a generation with the compaction switched off must give the same tokens."""
+    cfg, m, ids, seq, hist, trace = full
+    eng = m.hip_engine()
+    assert eng.prune_last_layer
+    x = hist[40].to(DEV)
+    lo, hi = P + 2 * BL - 1, P + 3 * BL - 1                                # source rows of block 2's window
+    full_hn = eng.forward_hidden(x).view(B, L, -1)[:, lo:hi].clone()
+    part_hn = eng.forward_hidden(x, need=(lo, hi)).view(B, L, -1)[:, lo:hi].clone()
+    diff = (full_hn.float() - part_hn.float()).abs().max().item()
+    print(f"compact tail vs full forward: max |diff| of the final-normed rows {diff:.3g} (scale {full_hn.float().abs().mean().item():.3g})")
+    assert torch.equal(full_hn, part_hn)
+    kw = dict(mask_token_id=cfg.mask_token_id, max_new_tokens=64, steps=32, alg="entropy", temperature=0.0, block_length=BL)
+    a = m.diffusion_generate(ids[:8].to(DEV), **kw)
+    eng.prune_last_layer = False
+    try:
+        b = m.diffusion_generate(ids[:8].to(DEV), **kw)
+    finally:
+        eng.prune_last_layer = True
+    assert torch.equal(a, b)
+
+
 def test_c2_teacher_forced_sample_vs_cpu_oracle(full):
     from parity import teacher_forced
     cfg, m, ids, seq, hist, trace = full
