@@ -19,3 +19,10 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"))
+
+
+@pytest.fixture(scope="session")
+def separated():
+    """Well-separated greedy runs of the reference (tests/golden/make_golden.py separated, section G9)."""
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "separated_vectors.npz"))

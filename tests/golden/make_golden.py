@@ -310,5 +310,124 @@ def main():
     print(f"wrote reference_vectors.npz ({sz/1e6:.2f} MB, {len(out)} arrays)")
 
 
+# ---- G9: WELL-SEPARATED greedy cases, for the free-running token-exact check on the GPU.
+#  bf16 confidences of a random-init model are tie-dominated, so most free runs on another device diverge at a
+#  near-tie and say nothing about the implementation.  Here prompts are SEARCHED for runs of the reference that are
+#  well posed: no step's k-th and (k+1)-th confidences are equal, and the final tokens and every per-step history
+#  survive N_PERT reruns with noise added to the logits before their bf16 rounding - a coherent part (a random
+#  perturbation of the final hidden state carried through the lm-head, COHERENT_FRAC x std(logits)) plus independent
+#  uniform noise of +-NOISE_FRAC x std(logits).  (A bf16 forward on another device differs from the CPU one by 0.4 % of
+#  the logit std on average, 2.6 % at most: tests/test_hip_e2e.py forward check.)  I.e. no decision sits on a near-tie.  The selection criterion is this CPU-side stability only; nothing from the HIP path enters
+#  it.  The stored vectors are the UNPERTURBED reference outputs (the reference itself is run on each kept prompt).
+N_PERT = 16
+NOISE_FRAC = 0.01
+COHERENT_FRAC = 0.02      # entropy moves by ~0.02 (std) / 0.06 (max): what the HIP path's bf16 forward shows
+
+
+def stable_under_noise(sd, d, ids, base, kw):
+    W = sd["lm_head.weight"].float()
+    for r in range(N_PERT):
+        g = torch.Generator().manual_seed(7000 + r)
+
+        def hook(i, x, logits, g=g):
+            lf = logits.float()
+            sigma = lf.std()
+            # (a) a perturbation of the final hidden state, carried through the lm-head: moves a row's logits coherently
+            #     (what an accumulation-order difference in the decoder does); scaled to COHERENT_FRAC x std(logits)
+            dh = torch.randn(lf.shape[0], lf.shape[1], W.shape[1], generator=g)
+            coh = dh @ W.t()
+            coh = coh * (COHERENT_FRAC * sigma / coh.std())
+            # (b) independent noise on every logit
+            ind = (torch.rand(lf.shape, generator=g) * 2 - 1) * (NOISE_FRAC * sigma)
+            return (lf + coh + ind).to(logits.dtype)
+        tr = ref_cpu.diffusion_generate(sd, d, ids, logits_hook=hook, **kw)
+        if not (torch.equal(tr.sequences, base.sequences) and all(torch.equal(a, b) for a, b in zip(tr.history, base.history))):
+            return False
+    return True
+
+
+def no_exact_boundary_tie(base):
+    """torch.topk's order among equal keys is unspecified: a run whose k-th and (k+1)-th confidences are
+    EQUAL is ill posed whatever the noise says."""
+    for i, k in enumerate(base.k):
+        if not k:
+            continue
+        key = base.key[i]
+        for b in range(key.shape[0]):
+            v = key[b][base.cand[i][b]].sort(descending=True).values
+            if k < v.numel() and v[k - 1] == v[k]:
+                return False
+    return True
+
+
+SEP_SHAPES = (dict(B=2, P=8, G=8, steps=2), dict(B=1, P=8, G=8, steps=4), dict(B=2, P=8, G=8, steps=4),
+              dict(B=1, P=12, G=16, steps=8))
+SEP_ALGS = ("entropy", "maskgit_plus", "topk_margin")
+
+
+def search_separated(alg, path, trials=1500, per_shape=2):
+    """One alg's search (run the three algs as three processes: python make_golden.py separated-search <alg> <npz>)."""
+    torch.set_num_threads(2)
+    out = {}
+    d = ref_cpu.Dims(**SMALL)
+    sd32 = ref_cpu.make_state_dict(d, 22, torch.float32, lm_head_gain=8.0, norm_jitter=0.1)
+    sd = {k: v.to(torch.bfloat16) for k, v in sd32.items()}
+    m = ref_model(d, sd32, torch.bfloat16)
+    kept = 0
+    for si, shp in enumerate(SEP_SHAPES):
+        found = 0
+        for trial in range(trials):
+            if found >= per_shape:
+                break
+            seed = 100000 + 10000 * si + trial
+            ids = prompts(d, shp["B"], shp["P"], seed)
+            kw = dict(max_new_tokens=shp["G"], steps=shp["steps"], alg=alg)
+            base = ref_cpu.diffusion_generate(sd, d, ids, trace=True, **kw)
+            if not no_exact_boundary_tie(base):
+                continue
+            if len(set(base.sequences[:, shp["P"]:].reshape(-1).tolist())) < 3:
+                continue                                     # degenerate: the same token everywhere
+            if not stable_under_noise(sd, d, ids, base, kw):
+                continue
+            with torch.no_grad():
+                ref = m.diffusion_generate(ids, generation_config=gen_cfg(d, **kw))
+            hist = torch.stack(list(ref.history))
+            assert torch.equal(ref.sequences, base.sequences) and torch.equal(hist, torch.stack(base.history)), \
+                "oracle diverges from the reference"
+            key = f"sep_small_bf16_{alg}_{kept}"
+            out[key + "_ids"] = ids.numpy()
+            out[key + "_seq"] = ref.sequences.numpy()
+            out[key + "_hist"] = hist.numpy().astype(np.int32)
+            out[key + "_meta"] = np.array(repr(dict(dims=SMALL, dtype="torch.bfloat16", weight_seed=22, gain=8.0, norm_jitter=0.1,
+                                                    prompt_seed=seed, n_pert=N_PERT, noise_frac=NOISE_FRAC,
+                                                    coherent_frac=COHERENT_FRAC, alg=alg, **shp)))
+            print(f"  {key}: shape {shp} prompt seed {seed} (trial {trial}) stable under {N_PERT} perturbed reruns", flush=True)
+            found += 1
+            kept += 1
+    print(f"{alg}: {kept} separated cases", flush=True)
+    np.savez_compressed(path, **out)
+
+
+def main_separated():
+    """Runs the three searches side by side and merges their vectors into separated_vectors.npz."""
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "separated-search", alg, os.path.join(tmp, alg + ".npz")])
+             for alg in SEP_ALGS]
+    assert all(p.wait() == 0 for p in procs)
+    out = {}
+    for alg in SEP_ALGS:
+        z = np.load(os.path.join(tmp, alg + ".npz"))
+        out.update({k: z[k] for k in z.files})
+    np.savez_compressed(os.path.join(HERE, "separated_vectors.npz"), **out)
+    print(f"wrote separated_vectors.npz ({len(out)} arrays)")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "separated":
+        main_separated()
+    elif len(sys.argv) > 3 and sys.argv[1] == "separated-search":
+        search_separated(sys.argv[2], sys.argv[3])
+    else:
+        main()

@@ -225,3 +225,20 @@ def test_teacher_forced_step_subset_equals_full_walk():
     for n, i in enumerate(pick):
         assert torch.equal(sub.history[n], free.history[i])
         assert sub.k[n] == free.k[i] and torch.equal(sub.conf[n], free.conf[i]) and torch.equal(sub.cand[n], free.cand[i])
+
+
+def test_separated_vectors_token_exact(separated):
+    """Section G9 of make_golden.py: the oracle reproduces the reference's well-separated greedy runs."""
+    keys = sorted(k[:-5] for k in separated.files if k.endswith("_meta"))
+    assert len(keys) >= 6
+    sd = d = None
+    for key in keys:
+        meta = _meta(separated, key + "_meta")
+        if sd is None:
+            d = ref_cpu.Dims(**meta["dims"])
+            sd32 = ref_cpu.make_state_dict(d, meta["weight_seed"], torch.float32, lm_head_gain=meta["gain"], norm_jitter=meta["norm_jitter"])
+            sd = {k: v.to(torch.bfloat16) for k, v in sd32.items()}
+        tr = ref_cpu.diffusion_generate(sd, d, torch.from_numpy(separated[key + "_ids"]), max_new_tokens=meta["G"],
+                                        steps=meta["steps"], alg=meta["alg"])
+        assert np.array_equal(tr.sequences.numpy(), separated[key + "_seq"]), key
+        assert np.array_equal(torch.stack(tr.history).numpy(), separated[key + "_hist"]), key
