@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=128)
     ap.add_argument("--block-length", type=int, default=32)
     ap.add_argument("--layers", type=int, default=28, help="debug only; anything but 28 marks the line invalid")
-    ap.add_argument("--cpu-steps", type=int, default=6, help="denoise steps timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=12, help="denoise steps timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
 

@@ -266,7 +266,7 @@ class HipEngine:
         """One sequence; returns (revealed, held_back) - the alg's one host read per step (the loop length depends on it)."""
         B, L = x.shape
         if B != 1:
-            raise CodaHipError("confidence_threshold works on one sequence")
+            raise _lib.CodaHipError("confidence_threshold works on one sequence")
         if getattr(self, "_thr_info", None) is None:
             self._thr_info = torch.zeros(2, dtype=torch.int32, device=x.device)
         _lib.call("coda_select_threshold", _ptr(x), _ptr(self.conf), _ptr(self.x0), L, lo, hi, self._mask_id, int(k),
