@@ -164,7 +164,8 @@ class HipEngine:
         T, s = B * L, self._stream()
         cos, sin = self._rope[L]
         ids = ids.contiguous()
-        prune = self.prune_last_layer and need is not None and 0 <= need[0] < need[1] <= L and (need[1] - need[0]) < L
+        # worth it while the two row compactions (2 x 4 KB per kept row) cost less than the skipped rows' GEMMs
+        prune = self.prune_last_layer and need is not None and 0 <= need[0] < need[1] <= L and 5 * (need[1] - need[0]) <= 4 * L
         _lib.call("coda_embed_gather", _ptr(ids), _ptr(self.embed), _ptr(self.h), T, self.V, self.H, s)
         scale = 1.0 / math.sqrt(self.d)
         for li, lw in enumerate(self.lw):
