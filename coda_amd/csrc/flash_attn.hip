@@ -2,7 +2,7 @@
 // Replaces attention.py:12-90 of the reference (repeat_kv + SDPA(is_causal=False), no mask: SURVEY F3).
 //
 // Work split: one workgroup = 4 waves; it walks query blocks qs, qs + qsplit, ... (128 queries each, 32 per
-// wave) of one (batch, q head).  K/V tiles of 64 keys are streamed through a double-buffered LDS ring by
+// wave) of one (batch, q head); from L = 512 on, 8 waves = the two q heads of a GQA pair on one K/V stream (PAIR).  K/V tiles of 64 keys are streamed through a double-buffered LDS ring by
 // LDS-DMA; the ring and the Q prefetch run CONTINUOUSLY across query blocks, so the fixed cost of a workgroup
 // (launch, first Q/K/V fetch: ~10 us, 44 % of the time at L = 384 with one block per workgroup) is paid once.
 //
@@ -42,16 +42,21 @@ struct AttnArgs {
 
 __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
-__global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnArgs a) {
+// PAIR: one workgroup = 8 waves = TWO query heads of one K/V head (GQA): waves 0-3 head 2j, waves 4-7 head 2j+1, same
+// query block, ONE K/V stream through LDS for both (half the LDS-DMA and L2 traffic per query).
+template <bool PAIR>
+__global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void flash_attn_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave_all = threadIdx.x >> 6;
+    const int wave = wave_all & 3;            // position inside the head's 128-query block
     const int c = lane & 31, h = lane >> 5;
     // XCD-aware linear order: the (n_q / n_kv) query heads x query blocks that read one K/V head are consecutive
     // logical ids, so they run on ONE XCD at about the same time and the K/V head is fetched into that L2 once
     // (round-robin dispatch would otherwise spread them over 6 XCDs = 6 HBM/Infinity-Cache reads of every K/V byte)
     const int nqb = (a.L + QB - 1) / QB;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
-    const int qs = id % a.qsplit, head = (id / a.qsplit) % a.n_q, b = id / (a.qsplit * a.n_q);
+    const int heads_per_wg = PAIR ? 2 : 1, n_hg = a.n_q / heads_per_wg;
+    const int qs = id % a.qsplit, head = ((id / a.qsplit) % n_hg) * heads_per_wg + (PAIR ? (wave_all >> 2) : 0), b = id / (a.qsplit * n_hg);
     const int kvh = head / (a.n_q / a.n_kv);
     const int L = a.L;
     const char* base = a.qkv + (size_t)b * L * a.ld_b;
@@ -74,13 +79,15 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnArgs a) {
     auto stage = [&](int t, int buf) {
         char* kd = lds + buf * TILE;
         char* vd = lds + (2 + buf) * TILE;
+        constexpr int NW = PAIR ? 8 : 4;              // waves sharing the 16 pieces of a tile
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (i * 4 + wave) * 4 + dma_r;
+        for (int i = 0; i < 16 / NW; ++i) {
+            const int piece = i * NW + wave_all;        // piece & 3 == wave: the swizzle term of dma_src_chunk
+            const int r = piece * 4 + dma_r;
             const int key = min(t * KB + r, L - 1);
             const size_t go = (size_t)key * a.ld_b + dma_src_chunk * 16;
-            glds16(kbase + go, kd + (i * 4 + wave) * 1024);
-            glds16(vbase + go, vd + (i * 4 + wave) * 1024);
+            glds16(kbase + go, kd + piece * 1024);
+            glds16(vbase + go, vd + piece * 1024);
         }
     };
 
@@ -310,10 +317,15 @@ extern "C" int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || (ld_qkv * 2) % 16 || (ld_out * 2) % 16) return CODA_ERR_ALIGN;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)flash_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)flash_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)flash_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS) != hipSuccess)
             return CODA_ERR_LAUNCH;
         attr_done = true;
     }
+    // two query heads per workgroup (one K/V stream through LDS for both): same results bit for bit; measured
+    // (tools/attn_bench.py) -5 % at L = 768, -9 % at L = 2048, no change at L = 384, where the K/V stream is not the bound
+    bool pair = (n_q / n_kv) % 2 == 0 && L >= 512;
+    if (const char* e = getenv("CODA_ATTN_PAIR")) pair = atoi(e) != 0 && (n_q / n_kv) % 2 == 0;   // A/B benches and tests
     AttnArgs a;
     a.qkv = (const char*)qkv; a.ld_b = ld_qkv * 2;
     a.out = (char*)out; a.ldo_b = ld_out * 2;
@@ -329,12 +341,14 @@ extern "C" int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             slots = 2 * cus;
     }
+    const int wg_slots = pair ? slots / 2 : slots;
+    const int n_hg = pair ? n_q / 2 : n_q;
     const int nqb = (L + QB - 1) / QB, ntile = (L + KB - 1) / KB;
     double best = 1e30;
     a.qsplit = 1;
     for (int qsp = 1; qsp <= nqb; ++qsp) {
-        const long long wgs = (long long)B * n_q * qsp;
-        const double rounds = (double)((wgs + slots - 1) / slots);
+        const long long wgs = (long long)B * n_hg * qsp;
+        const double rounds = (double)((wgs + wg_slots - 1) / wg_slots);
         const double cost = rounds * (9.7 + 1.95 * ntile * ((nqb + qsp - 1) / qsp));
         if (cost < best) { best = cost; a.qsplit = qsp; }
     }
@@ -345,7 +359,8 @@ extern "C" int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void
 #ifdef CODA_CLOCK_PROBE
     a.probe = g_attn_probe;
 #endif
-    hipLaunchKernelGGL(flash_attn_kernel, dim3(a.qsplit * n_q * B), dim3(256), ATTN_LDS, (hipStream_t)stream, a);
+    if (pair) hipLaunchKernelGGL(flash_attn_kernel<true>, dim3(a.qsplit * n_hg * B), dim3(512), ATTN_LDS, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(flash_attn_kernel<false>, dim3(a.qsplit * n_q * B), dim3(256), ATTN_LDS, (hipStream_t)stream, a);
     CODA_CHECK_LAUNCH("flash_attn");
     return CODA_OK;
 }

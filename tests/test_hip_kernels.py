@@ -294,6 +294,24 @@ def test_flash_attention(B, L, n_q, n_kv):
     assert err < 2e-2, err
 
 
+@pytest.mark.parametrize("B,L,n_q,n_kv", [(2, 100, 4, 2), (3, 517, 4, 1), (4, 640, 16, 8), (1, 2048, 16, 8)])
+def test_flash_attention_head_pairs_bit_identical(B, L, n_q, n_kv, monkeypatch):
+    """From L = 512 on a workgroup runs the two query heads of a GQA pair on one K/V stream (8 waves); the per-wave
+    arithmetic is the same, so both variants must agree bit for bit (CODA_ATTN_PAIR forces either)."""
+    g = torch.Generator().manual_seed(13)
+    d, T = 128, B * L
+    qkv = torch.randn(T, (n_q + 2 * n_kv) * d, generator=g).to(BF).to(DEV)
+    outs = []
+    for pair in ("0", "1"):
+        monkeypatch.setenv("CODA_ATTN_PAIR", pair)
+        out = torch.full((T, n_q * d), float("nan"), device=DEV, dtype=BF)
+        _lib.call("coda_flash_attn_noncausal", _p(qkv), qkv.stride(0), _p(out), n_q * d, B, L, n_q, n_kv, 1.0 / math.sqrt(d), _s())
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert not torch.isnan(outs[1].float()).any()
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_flash_attention_exact_uniform():
     """All-equal scores: softmax is uniform, so O = mean(V); with integer V this checks the V transposed-read
     mapping and the P/V k-order pairing without tolerance slack."""
