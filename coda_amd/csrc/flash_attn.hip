@@ -26,7 +26,7 @@ namespace {
 constexpr int QB = 128;      // queries per workgroup
 constexpr int KB = 64;       // keys per tile
 constexpr int TILE = KB * 256;                 // 16 KiB
-constexpr int ATTN_LDS = 4 * TILE;             // K[2] + V[2]
+constexpr int attn_lds(int ns) { return 2 * ns * TILE; }   // K[ns] + V[ns]
 constexpr float RESCALE_THR = 6.0f;            // log2 units: P <= 64 between rescales
 
 struct AttnArgs {
@@ -44,7 +44,9 @@ __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >>
 
 // PAIR: one workgroup = 8 waves = TWO query heads of one K/V head (GQA): waves 0-3 head 2j, waves 4-7 head 2j+1, same
 // query block, ONE K/V stream through LDS for both (half the LDS-DMA and L2 traffic per query).
-template <bool PAIR>
+// NS: stages of the K/V ring (prefetch distance NS - 1 tiles).  4 waves: 2 stages (64 KiB, two workgroups per CU);
+// PAIR has the CU to itself and takes a deeper ring.
+template <bool PAIR, int NS>
 __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void flash_attn_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wave_all = threadIdx.x >> 6;
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void flash_attn_ker
     const int dma_src_chunk = (lane & 15) ^ ((dma_r << 2) | wave); // swz(row) for row = (i*4+wave)*4 + dma_r
     auto stage = [&](int t, int buf) {
         char* kd = lds + buf * TILE;
-        char* vd = lds + (2 + buf) * TILE;
+        char* vd = lds + (NS + buf) * TILE;
         constexpr int NW = PAIR ? 8 : 4;              // waves sharing the 16 pieces of a tile
 #pragma unroll
         for (int i = 0; i < 16 / NW; ++i) {
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void flash_attn_ker
     // (register double buffers kA/kB, vA/vB); the key mask runs only on a ragged last tile.
     auto tile = [&](int t, int buf, int next_qblk, bool ragged) {
         const char* kt = lds + buf * TILE;
-        const char* vt = lds + (2 + buf) * TILE;
+        const char* vt = lds + (NS + buf) * TILE;
         bf16x8_t kA[4], kB[4], vA[4], vB[4];
         f32x16_t s[2];
 #pragma unroll
@@ -238,8 +240,28 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void flash_attn_ker
 #endif
     const int nt = (L + KB - 1) / KB;
     const int n_full = L / KB;                     // tiles without a ragged edge
-    int gt = 0;                                    // tiles consumed so far: the ring position
-    stage(0, 0);
+    // The ring runs over the FLAT tile sequence of all query blocks this workgroup walks (same K/V head: block after
+    // block restarts at key tile 0).  Flat tile f lives in stage f % NS; its DMA is issued NS - 1 tiles ahead.
+    int nblk = 0;
+    for (int qblk = qs; qblk < nqb; qblk += a.qsplit) ++nblk;
+    const int total = nblk * nt;
+    constexpr int DMA_OPS = PAIR ? 4 : 8;          // LDS-DMA instructions per wave and stage
+    int f = 0;                                     // flat tile index = ring position
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < total) stage(p % nt, p % NS);
+    auto wait_dma = [](int n) {                    // s_waitcnt takes an immediate
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+            case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
     for (int qblk = qs; qblk < nqb; qblk += a.qsplit) {
         const bool more = qblk + a.qsplit < nqb;
 #pragma unroll
@@ -248,21 +270,17 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void flash_attn_ker
             for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
         m_run = -1e30f;
         l_run = 0.f;
-        for (int t = 0; t < nt; ++t) {
-            // the next tile's DMA must have landed.  On the first tile of a later block the 8 youngest vector-memory
-            // operations are the previous block's output stores (or, for a wave that stored nothing, its Q
-            // prefetch, which the compiler waits for before use): they may stay in flight, the DMA is older
-            if (t == 0 && qblk != qs) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int t = 0; t < nt; ++t, ++f) {
+            // Tile f's DMA must have landed.  Vector-memory operations retire in issue order, so it is enough to allow
+            // as many outstanding as were ISSUED after it: the DMA of the (up to NS - 2) later stages, and - while the
+            // previous block's end lies inside that window - 8 more: its output stores, or for a wave that stored
+            // nothing the Q prefetch (8 loads, issued before the stores and needed by this tile anyway)
+            const int later = min(NS - 2, total - 1 - f);
+            wait_dma(DMA_OPS * later + ((qblk != qs && t <= NS - 2) ? 8 : 0));
             __syncthreads();
-            if (t + 1 < nt) {
-                stage(t + 1, (gt + 1) & 1);
-            } else if (more) {
-                stage(0, (gt + 1) & 1);            // same K/V head: the next block starts again at key tile 0
-            }
+            if (f + NS - 1 < total) stage((f + NS - 1) % nt, (f + NS - 1) % NS);
             const int nq = (t + 1 == nt && more) ? qblk + a.qsplit : -1;
-            tile(t, gt & 1, nq, t >= n_full);
-            ++gt;
+            tile(t, f % NS, nq, t >= n_full);
         }
 
         // ---- epilogue: normalise, store bf16.  reg i of d-block db: d = 32 db + (i&3) + 8 (i>>2) + 4 h, i.e. a
@@ -315,15 +333,14 @@ extern "C" int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void
     if ((long long)B * n_q * ((L + QB - 1) / QB) > 0x7fffffffLL) return CODA_ERR_SHAPE;
     if (!qkv || !out) return CODA_ERR_ARG;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || (ld_qkv * 2) % 16 || (ld_out * 2) % 16) return CODA_ERR_ALIGN;
+    constexpr int NS_PAIR = 2;     // 3 and 4 stages measured: no change at L = 384 .. 2048 (the DMA latency is covered)
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)flash_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)flash_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)flash_attn_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(2)) != hipSuccess ||
+            hipFuncSetAttribute((const void*)flash_attn_kernel<true, NS_PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(NS_PAIR)) != hipSuccess)
             return CODA_ERR_LAUNCH;
         attr_done = true;
     }
-    // two query heads per workgroup (one K/V stream through LDS for both): same results bit for bit; measured
-    // (tools/attn_bench.py) -5 % at L = 768, -9 % at L = 2048, no change at L = 384, where the K/V stream is not the bound
     bool pair = (n_q / n_kv) % 2 == 0 && L >= 512;
     if (const char* e = getenv("CODA_ATTN_PAIR")) pair = atoi(e) != 0 && (n_q / n_kv) % 2 == 0;   // A/B benches and tests
     AttnArgs a;
@@ -359,8 +376,8 @@ extern "C" int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void
 #ifdef CODA_CLOCK_PROBE
     a.probe = g_attn_probe;
 #endif
-    if (pair) hipLaunchKernelGGL(flash_attn_kernel<true>, dim3(a.qsplit * n_hg * B), dim3(512), ATTN_LDS, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(flash_attn_kernel<false>, dim3(a.qsplit * n_q * B), dim3(256), ATTN_LDS, (hipStream_t)stream, a);
+    if (pair) hipLaunchKernelGGL((flash_attn_kernel<true, NS_PAIR>), dim3(a.qsplit * n_hg * B), dim3(512), attn_lds(NS_PAIR), (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((flash_attn_kernel<false, 2>), dim3(a.qsplit * n_q * B), dim3(256), attn_lds(2), (hipStream_t)stream, a);
     CODA_CHECK_LAUNCH("flash_attn");
     return CODA_OK;
 }
