@@ -362,19 +362,26 @@ def no_exact_boundary_tie(base):
 
 SEP_SHAPES = (dict(B=2, P=8, G=8, steps=2), dict(B=1, P=8, G=8, steps=4), dict(B=2, P=8, G=8, steps=4),
               dict(B=1, P=12, G=16, steps=8))
+# the GPU tests' "mid" model at T = B * L >= 256 tokens: the persistent GEMM engines and the fused QKV + q/k-norm + RoPE
+# epilogue are on the path (the small shapes above stay on the 128 x 128 engine)
+MID = dict(vocab=8192, hidden=512, inter=1024, heads=4, kv_heads=2, head_dim=128, layers=3, mask_id=8191, pad_id=8000,
+           max_pos=4096)
+MID_SHAPES = (dict(B=8, P=24, G=8, steps=2), dict(B=8, P=28, G=4, steps=2), dict(B=4, P=60, G=4, steps=2))
+SEP_MODELS = {"small": (SMALL, 22, SEP_SHAPES), "mid": (MID, 31, MID_SHAPES)}
 SEP_ALGS = ("entropy", "maskgit_plus", "topk_margin")
 
 
-def search_separated(alg, path, trials=1500, per_shape=2):
-    """One alg's search (run the three algs as three processes: python make_golden.py separated-search <alg> <npz>)."""
+def search_separated(model, alg, path, trials=1500, per_shape=2):
+    """One model's and alg's search (python make_golden.py separated-search <model> <alg> <npz>)."""
     torch.set_num_threads(2)
     out = {}
-    d = ref_cpu.Dims(**SMALL)
-    sd32 = ref_cpu.make_state_dict(d, 22, torch.float32, lm_head_gain=8.0, norm_jitter=0.1)
+    dims_kw, wseed, shapes = SEP_MODELS[model]
+    d = ref_cpu.Dims(**dims_kw)
+    sd32 = ref_cpu.make_state_dict(d, wseed, torch.float32, lm_head_gain=8.0, norm_jitter=0.1)
     sd = {k: v.to(torch.bfloat16) for k, v in sd32.items()}
     m = ref_model(d, sd32, torch.bfloat16)
     kept = 0
-    for si, shp in enumerate(SEP_SHAPES):
+    for si, shp in enumerate(shapes):
         found = 0
         for trial in range(trials):
             if found >= per_shape:
@@ -394,40 +401,46 @@ def search_separated(alg, path, trials=1500, per_shape=2):
             hist = torch.stack(list(ref.history))
             assert torch.equal(ref.sequences, base.sequences) and torch.equal(hist, torch.stack(base.history)), \
                 "oracle diverges from the reference"
-            key = f"sep_small_bf16_{alg}_{kept}"
+            key = f"sep_{model}_bf16_{alg}_{kept}"
             out[key + "_ids"] = ids.numpy()
             out[key + "_seq"] = ref.sequences.numpy()
             out[key + "_hist"] = hist.numpy().astype(np.int32)
-            out[key + "_meta"] = np.array(repr(dict(dims=SMALL, dtype="torch.bfloat16", weight_seed=22, gain=8.0, norm_jitter=0.1,
+            out[key + "_meta"] = np.array(repr(dict(dims=dims_kw, dtype="torch.bfloat16", weight_seed=wseed, gain=8.0, norm_jitter=0.1,
                                                     prompt_seed=seed, n_pert=N_PERT, noise_frac=NOISE_FRAC,
                                                     coherent_frac=COHERENT_FRAC, alg=alg, **shp)))
             print(f"  {key}: shape {shp} prompt seed {seed} (trial {trial}) stable under {N_PERT} perturbed reruns", flush=True)
             found += 1
             kept += 1
-    print(f"{alg}: {kept} separated cases", flush=True)
+    print(f"{model} {alg}: {kept} separated cases", flush=True)
     np.savez_compressed(path, **out)
 
 
-def main_separated():
-    """Runs the three searches side by side and merges their vectors into separated_vectors.npz."""
+def main_separated(models):
+    """Runs the searches of the given models (three algs side by side each) and merges their vectors into
+    separated_vectors.npz; vectors of models not searched in this run are kept."""
     import subprocess
     import tempfile
     tmp = tempfile.mkdtemp()
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "separated-search", alg, os.path.join(tmp, alg + ".npz")])
-             for alg in SEP_ALGS]
-    assert all(p.wait() == 0 for p in procs)
+    dst = os.path.join(HERE, "separated_vectors.npz")
     out = {}
-    for alg in SEP_ALGS:
-        z = np.load(os.path.join(tmp, alg + ".npz"))
-        out.update({k: z[k] for k in z.files})
-    np.savez_compressed(os.path.join(HERE, "separated_vectors.npz"), **out)
+    if os.path.exists(dst):
+        z = np.load(dst)
+        out = {k: z[k] for k in z.files if not any(k.startswith(f"sep_{mo}_") for mo in models)}
+    for model in models:
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "separated-search", model, alg,
+                                   os.path.join(tmp, f"{model}_{alg}.npz")]) for alg in SEP_ALGS]
+        assert all(p.wait() == 0 for p in procs)
+        for alg in SEP_ALGS:
+            z = np.load(os.path.join(tmp, f"{model}_{alg}.npz"))
+            out.update({k: z[k] for k in z.files})
+    np.savez_compressed(dst, **out)
     print(f"wrote separated_vectors.npz ({len(out)} arrays)")
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "separated":
-        main_separated()
-    elif len(sys.argv) > 3 and sys.argv[1] == "separated-search":
-        search_separated(sys.argv[2], sys.argv[3])
+        main_separated(sys.argv[2:] or list(SEP_MODELS))
+    elif len(sys.argv) > 4 and sys.argv[1] == "separated-search":
+        search_separated(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         main()

@@ -231,13 +231,15 @@ def test_separated_vectors_token_exact(separated):
     """Section G9 of make_golden.py: the oracle reproduces the reference's well-separated greedy runs."""
     keys = sorted(k[:-5] for k in separated.files if k.endswith("_meta"))
     assert len(keys) >= 6
-    sd = d = None
+    models = {}
     for key in keys:
         meta = _meta(separated, key + "_meta")
-        if sd is None:
+        mk = (repr(meta["dims"]), meta["weight_seed"])
+        if mk not in models:
             d = ref_cpu.Dims(**meta["dims"])
             sd32 = ref_cpu.make_state_dict(d, meta["weight_seed"], torch.float32, lm_head_gain=meta["gain"], norm_jitter=meta["norm_jitter"])
-            sd = {k: v.to(torch.bfloat16) for k, v in sd32.items()}
+            models[mk] = (d, {k: v.to(torch.bfloat16) for k, v in sd32.items()})
+        d, sd = models[mk]
         tr = ref_cpu.diffusion_generate(sd, d, torch.from_numpy(separated[key + "_ids"]), max_new_tokens=meta["G"],
                                         steps=meta["steps"], alg=meta["alg"])
         assert np.array_equal(tr.sequences.numpy(), separated[key + "_seq"]), key
