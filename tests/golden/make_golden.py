@@ -367,7 +367,12 @@ SEP_SHAPES = (dict(B=2, P=8, G=8, steps=2), dict(B=1, P=8, G=8, steps=4), dict(B
 MID = dict(vocab=8192, hidden=512, inter=1024, heads=4, kv_heads=2, head_dim=128, layers=3, mask_id=8191, pad_id=8000,
            max_pos=4096)
 MID_SHAPES = (dict(B=8, P=24, G=8, steps=2), dict(B=8, P=28, G=4, steps=2), dict(B=4, P=60, G=4, steps=2))
-SEP_MODELS = {"small": (SMALL, 22, SEP_SHAPES), "mid": (MID, 31, MID_SHAPES)}
+# windowed mode (block_length): the reference has no implementation of it (F2), so these vectors
+# are the ORACLE's outputs (meta["source"] says so); the selection rule is the same
+WIN_SMALL_SHAPES = (dict(B=2, P=8, G=8, steps=4, block_length=4), dict(B=1, P=8, G=16, steps=8, block_length=8))
+WIN_MID_SHAPES = (dict(B=8, P=24, G=8, steps=4, block_length=4), dict(B=4, P=56, G=8, steps=4, block_length=4))
+SEP_MODELS = {"small": (SMALL, 22, SEP_SHAPES), "mid": (MID, 31, MID_SHAPES),
+              "winsmall": (SMALL, 22, WIN_SMALL_SHAPES), "winmid": (MID, 31, WIN_MID_SHAPES)}
 SEP_ALGS = ("entropy", "maskgit_plus", "topk_margin")
 
 
@@ -389,6 +394,9 @@ def search_separated(model, alg, path, trials=1500, per_shape=2):
             seed = 100000 + 10000 * si + trial
             ids = prompts(d, shp["B"], shp["P"], seed)
             kw = dict(max_new_tokens=shp["G"], steps=shp["steps"], alg=alg)
+            windowed = shp.get("block_length") is not None
+            if windowed:
+                kw["block_length"] = shp["block_length"]
             base = ref_cpu.diffusion_generate(sd, d, ids, trace=True, **kw)
             if not no_exact_boundary_tie(base):
                 continue
@@ -396,18 +404,21 @@ def search_separated(model, alg, path, trials=1500, per_shape=2):
                 continue                                     # degenerate: the same token everywhere
             if not stable_under_noise(sd, d, ids, base, kw):
                 continue
-            with torch.no_grad():
-                ref = m.diffusion_generate(ids, generation_config=gen_cfg(d, **kw))
-            hist = torch.stack(list(ref.history))
-            assert torch.equal(ref.sequences, base.sequences) and torch.equal(hist, torch.stack(base.history)), \
-                "oracle diverges from the reference"
+            if windowed:
+                seq, hist, source = base.sequences, torch.stack(base.history), "oracle (windowed mode has no reference implementation)"
+            else:
+                with torch.no_grad():
+                    ref = m.diffusion_generate(ids, generation_config=gen_cfg(d, **kw))
+                seq, hist, source = ref.sequences, torch.stack(list(ref.history)), "reference"
+                assert torch.equal(seq, base.sequences) and torch.equal(hist, torch.stack(base.history)), \
+                    "oracle diverges from the reference"
             key = f"sep_{model}_bf16_{alg}_{kept}"
             out[key + "_ids"] = ids.numpy()
-            out[key + "_seq"] = ref.sequences.numpy()
+            out[key + "_seq"] = seq.numpy()
             out[key + "_hist"] = hist.numpy().astype(np.int32)
             out[key + "_meta"] = np.array(repr(dict(dims=dims_kw, dtype="torch.bfloat16", weight_seed=wseed, gain=8.0, norm_jitter=0.1,
                                                     prompt_seed=seed, n_pert=N_PERT, noise_frac=NOISE_FRAC,
-                                                    coherent_frac=COHERENT_FRAC, alg=alg, **shp)))
+                                                    coherent_frac=COHERENT_FRAC, alg=alg, source=source, **shp)))
             print(f"  {key}: shape {shp} prompt seed {seed} (trial {trial}) stable under {N_PERT} perturbed reruns", flush=True)
             found += 1
             kept += 1

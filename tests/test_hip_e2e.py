@@ -125,7 +125,8 @@ def test_separated_golden_free_running_token_exact(small, mid, separated):
     """Greedy runs of the REFERENCE (bf16, CPU) that are well posed - no decision on a near-tie: no step's k-th and
     (k+1)-th confidences are equal and the whole run survives 16 reruns with forward-sized noise on the logits
     (make_golden.py section G9; the selection uses CPU-side stability only, nothing from the HIP path).
-    The HIP path, free running with its default settings, must give the reference's tokens at every step, exactly."""
+    The HIP path, free running with its default settings, must give the reference's tokens at every step, exactly.
+    Windowed cases (block_length; no reference implementation) hold the oracle's outputs, same selection rule."""
     keys = sorted(k[:-5] for k in separated.files if k.endswith("_meta"))
     assert len(keys) >= 6
     for key in keys:
@@ -135,12 +136,13 @@ def test_separated_golden_free_running_token_exact(small, mid, separated):
         assert meta["gain"] == 8.0 and meta["dims"] in (SMALL, MID) and meta["weight_seed"] == (22 if meta["dims"] == SMALL else 31)
         ids = torch.from_numpy(separated[key + "_ids"])
         out = m.diffusion_generate(ids.to(DEV), max_new_tokens=meta["G"], steps=meta["steps"], alg=meta["alg"],
-                                   mask_token_id=d.mask_id, return_dict_in_generate=True, output_history=True)
+                                   block_length=meta.get("block_length"), mask_token_id=d.mask_id,
+                                   return_dict_in_generate=True, output_history=True)
         ref_seq = torch.from_numpy(separated[key + "_seq"])
         ref_hist = torch.from_numpy(separated[key + "_hist"]).long()
         hist = torch.stack([h.cpu() for h in out.history])
         steps_equal = int((hist == ref_hist).all(dim=(1, 2)).sum())
-        print(f"separated {key} alg={meta['alg']} B={meta['B']} G={meta['G']} steps={meta['steps']}: "
+        print(f"separated {key} alg={meta['alg']} B={meta['B']} G={meta['G']} steps={meta['steps']} block={meta.get('block_length')}: "
               f"{steps_equal}/{meta['steps']} step states identical, final tokens equal: {torch.equal(out.sequences.cpu(), ref_seq)}")
         assert torch.equal(out.sequences.cpu(), ref_seq), key
         assert torch.equal(hist, ref_hist), key

@@ -241,6 +241,6 @@ def test_separated_vectors_token_exact(separated):
             models[mk] = (d, {k: v.to(torch.bfloat16) for k, v in sd32.items()})
         d, sd = models[mk]
         tr = ref_cpu.diffusion_generate(sd, d, torch.from_numpy(separated[key + "_ids"]), max_new_tokens=meta["G"],
-                                        steps=meta["steps"], alg=meta["alg"])
+                                        steps=meta["steps"], alg=meta["alg"], block_length=meta.get("block_length"))
         assert np.array_equal(tr.sequences.numpy(), separated[key + "_seq"]), key
         assert np.array_equal(torch.stack(tr.history).numpy(), separated[key + "_hist"]), key
