@@ -3,6 +3,13 @@
 #include "coda_common.h"
 
 void coda_set_last_error(const char* what, hipError_t e);
+void coda_set_last_error_msg(const char* msg);   // argument errors that deserve words (read back by coda_last_error)
+
+// Per-device facts, read once per device (abi_misc.hip): the CU count of the CURRENT device, and the
+// hipFuncAttributeMaxDynamicSharedMemorySize grant for (current device, kernel).  A process may hold engines on
+// several GPUs: every launcher asks for the device that is current at the call.
+int coda_device_cus();
+int coda_ensure_dyn_lds(const void* func, int bytes);   // CODA_OK or CODA_ERR_LAUNCH
 
 #define CODA_CHECK_LAUNCH(what)                                  \
     do {                                                         \

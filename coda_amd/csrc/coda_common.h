@@ -46,6 +46,18 @@ __device__ __forceinline__ void round_bf16_pair(float& a, float& b) {
     b = bf16_hi(pk);
 }
 
+// Counter-based uniform in (0, 1): a pure function of (seed, row key, index).  All sampling noise that is not injected
+// by the caller comes from here (token noise: row key = flat position of the candidate, index = vocabulary id;
+// selection / origin noise: index = 0xFFFFFFFF / 0xFFFFFFFE), so a run is reproducible from its seed alone and no
+// RNG state or noise tensor lives in memory.
+__device__ __forceinline__ float coda_hash_uniform(unsigned int seed_lo, unsigned int seed_hi, unsigned int rowkey, unsigned int v) {
+    unsigned int h = v * 0x9E3779B1u ^ rowkey * 0x85EBCA77u ^ seed_lo;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    h += seed_hi;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
 // 16-byte asynchronous global -> LDS copy.  The LDS destination is wave-uniform base + lane*16.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const CODA_GLOBAL void*)gsrc, (CODA_LDS void*)lds_wave_base, 16, 0, 0);

@@ -22,14 +22,6 @@ __device__ __forceinline__ unsigned int fkey(float f) {       // larger float <-
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__device__ __forceinline__ float hash_uniform2(unsigned int seed_lo, unsigned int seed_hi, unsigned int rowkey, unsigned int v) {
-    unsigned int h = v * 0x9E3779B1u ^ rowkey * 0x85EBCA77u ^ seed_lo;
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    h += seed_hi;
-    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
-    return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
-}
-
 template <typename T>
 __device__ __forceinline__ T block_reduce(T v, T* red, int tid, T (*op)(T, T)) {
 #pragma unroll
@@ -80,6 +72,10 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
         return x;
     };
     const int kbits = a.is_bf16 ? 16 : 32;   // significant key bits (bf16 values have zero low halves)
+    // Keys are compared on their significant bits only: fkey() complements negative floats, so a negative bf16 value
+    // carries 0xFFFF in its low half while the radix prefix (kp / kk) has zeros there.
+    const unsigned int kmask = 0xffffffffu << (32 - kbits);
+    auto key_of = [&](float x) -> unsigned int { return fkey(x) & kmask; };
     // Every pass streams the row through fn(v, x).  16-byte loads (8 bf16 / 4 fp32 per lane) when the row is 16-byte
     // aligned: with 2-byte loads the passes were bound by the NUMBER of load instructions (one per element and lane),
     // 8x more than needed.  Reductions below do not depend on the order in which a thread meets its elements.
@@ -158,7 +154,7 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
             __syncthreads();
             const unsigned int hi_mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
             for_each([&](int, float x) {
-                const unsigned int k = fkey(x);
+                const unsigned int k = key_of(x);
                 if ((k & hi_mask) == prefix) {
                     atomicAdd(&hist_m[sub + ((k >> shift) & 255)], mass(x));
                     atomicAdd(&hist_i[sub + ((k >> shift) & 255)], 1);
@@ -228,13 +224,13 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
                         const u32x4_t raw = *(const u32x4_t*)(rp + (size_t)v * 2);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            if (fn(v + 2 * j, fkey(xform(bf16_lo(raw[j]))) == kp)) return;
-                            if (fn(v + 2 * j + 1, fkey(xform(bf16_hi(raw[j]))) == kp)) return;
+                            if (fn(v + 2 * j, key_of(xform(bf16_lo(raw[j]))) == kp)) return;
+                            if (fn(v + 2 * j + 1, key_of(xform(bf16_hi(raw[j]))) == kp)) return;
                         }
                     }
                 } else {
                     for (int v = v0; v < v1; ++v)
-                        if (fn(v, fkey(logit(v)) == kp)) return;
+                        if (fn(v, key_of(logit(v)) == kp)) return;
                 }
             };
             int mine = 0;
@@ -266,7 +262,7 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
             __syncthreads();
             const unsigned int hi_mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
             for_each([&](int, float x) {
-                const unsigned int k = fkey(x);
+                const unsigned int k = key_of(x);
                 if ((k & hi_mask) == prefix) atomicAdd(&hist_i[sub + ((k >> shift) & 255)], 1);
             });
             __syncthreads();
@@ -312,14 +308,14 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
     int barg = 0x7fffffff;
     const unsigned int rowkey = a.dst_pos ? (unsigned int)a.dst_pos[row] : (unsigned int)row;
     for_each([&](int v, float x) {
-        if (!kept(v, fkey(x))) return;
+        if (!kept(v, key_of(x))) return;
         const float d = x - mx, e = __expf(d);
         z += e;
         s += e * d;
         if (x == mx) { ++n_max; arg = min(arg, v); }
         else m2 = fmaxf(m2, x);
         if (sampled) {
-            const float q = a.noise ? a.noise[(size_t)row * V + v] : -__logf(hash_uniform2(a.seed_lo, a.seed_hi, rowkey, (unsigned)v));
+            const float q = a.noise ? a.noise[(size_t)row * V + v] : -__logf(coda_hash_uniform(a.seed_lo, a.seed_hi, rowkey, (unsigned)v));
             const float key = x - __logf(q);
             if (key > bkey || (key == bkey && v < barg)) { bkey = key; bl = x; barg = v; }
         }

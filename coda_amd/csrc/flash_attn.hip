@@ -19,7 +19,6 @@
 // ch ^ (((r&3)<<2) | ((r>>2)&3)): conflict-free for the b128 row reads and the transposed reads.
 #include "coda_abi_internal.h"
 #include <type_traits>
-#include <cstdlib>
 
 namespace {
 
@@ -326,23 +325,19 @@ extern "C" int coda_attn_probe(void* buf) {
 }
 #endif
 
-extern "C" int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void* out, long long ld_out, int B, int L,
-                                         int n_q, int n_kv, float scale, void* stream) {
+extern "C" int coda_flash_attn_noncausal_ex(const void* qkv, long long ld_qkv, void* out, long long ld_out, int B, int L,
+                                            int n_q, int n_kv, float scale, int pair_mode, int qsplit, void* stream) {
     if (B <= 0 || L <= 0 || n_q <= 0 || n_kv <= 0 || n_q % n_kv) return CODA_ERR_SHAPE;
     if (ld_qkv < (long long)(n_q + 2 * n_kv) * 128 || ld_out < (long long)n_q * 128) return CODA_ERR_SHAPE;
     if ((long long)B * n_q * ((L + QB - 1) / QB) > 0x7fffffffLL) return CODA_ERR_SHAPE;
     if (!qkv || !out) return CODA_ERR_ARG;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || (ld_qkv * 2) % 16 || (ld_out * 2) % 16) return CODA_ERR_ALIGN;
     constexpr int NS_PAIR = 2;     // 3 and 4 stages measured: no change at L = 384 .. 2048 (the DMA latency is covered)
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)flash_attn_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(2)) != hipSuccess ||
-            hipFuncSetAttribute((const void*)flash_attn_kernel<true, NS_PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(NS_PAIR)) != hipSuccess)
-            return CODA_ERR_LAUNCH;
-        attr_done = true;
-    }
+    if (coda_ensure_dyn_lds((const void*)flash_attn_kernel<false, 2>, attn_lds(2)) != CODA_OK ||
+        coda_ensure_dyn_lds((const void*)flash_attn_kernel<true, NS_PAIR>, attn_lds(NS_PAIR)) != CODA_OK)
+        return CODA_ERR_LAUNCH;
     bool pair = (n_q / n_kv) % 2 == 0 && L >= 512;
-    if (const char* e = getenv("CODA_ATTN_PAIR")) pair = atoi(e) != 0 && (n_q / n_kv) % 2 == 0;   // A/B benches and tests
+    if (pair_mode >= 0) pair = pair_mode != 0 && (n_q / n_kv) % 2 == 0;          // explicit per-call choice (A/B, tests)
     AttnArgs a;
     a.qkv = (const char*)qkv; a.ld_b = ld_qkv * 2;
     a.out = (char*)out; a.ldo_b = ld_out * 2;
@@ -351,13 +346,7 @@ extern "C" int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void
     // workgroups per (batch, head): few enough that each amortises its fixed cost over several query blocks, many
     // enough to fill 2 workgroups per CU in whole rounds.  Cost model (us, measured on this kernel): a round costs
     // 9.7 + 1.95 per K/V tile per query block
-    static int slots = 0;
-    if (slots == 0) {
-        int dev = 0, cus = 0;
-        slots = 512;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-            slots = 2 * cus;
-    }
+    const int slots = 2 * coda_device_cus();
     const int wg_slots = pair ? slots / 2 : slots;
     const int n_hg = pair ? n_q / 2 : n_q;
     const int nqb = (L + QB - 1) / QB, ntile = (L + KB - 1) / KB;
@@ -369,10 +358,7 @@ extern "C" int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void
         const double cost = rounds * (9.7 + 1.95 * ntile * ((nqb + qsp - 1) / qsp));
         if (cost < best) { best = cost; a.qsplit = qsp; }
     }
-    if (const char* e = getenv("CODA_ATTN_QSPLIT")) {            // A/B benches only
-        const int v = atoi(e);
-        if (v > 0) a.qsplit = v < nqb ? v : nqb;
-    }
+    if (qsplit > 0) a.qsplit = qsplit < nqb ? qsplit : nqb;      // explicit per-call choice (A/B benches)
 #ifdef CODA_CLOCK_PROBE
     a.probe = g_attn_probe;
 #endif
@@ -380,4 +366,9 @@ extern "C" int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void
     else hipLaunchKernelGGL((flash_attn_kernel<false, 2>), dim3(a.qsplit * n_q * B), dim3(256), attn_lds(2), (hipStream_t)stream, a);
     CODA_CHECK_LAUNCH("flash_attn");
     return CODA_OK;
+}
+
+extern "C" int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void* out, long long ld_out, int B, int L,
+                                         int n_q, int n_kv, float scale, void* stream) {
+    return coda_flash_attn_noncausal_ex(qkv, ld_qkv, out, ld_out, B, L, n_q, n_kv, scale, -1, 0, stream);
 }

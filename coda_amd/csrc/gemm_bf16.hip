@@ -277,13 +277,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs a) {
 template <int EPI>
 static int launch256(GemmArgs a, hipStream_t s) {
     using T = tile256::Tile<4>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                T::LDS_BYTES) != hipSuccess)
-            return CODA_ERR_LAUNCH;
-        attr_done = true;
-    }
+    if (coda_ensure_dyn_lds((const void*)gemm256_bf16_kernel<EPI>, T::LDS_BYTES) != CODA_OK) return CODA_ERR_LAUNCH;
     a.tiles_m = (a.M + T::BM - 1) / T::BM;
     a.tiles_n = (a.N + T::BN - 1) / T::BN;
     hipLaunchKernelGGL(gemm256_bf16_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(512), T::LDS_BYTES, s, a);
@@ -685,19 +679,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
 template <int EPI, int MTH = 4, bool XDEEP = false>
 static int launch256p(GemmArgs a, hipStream_t s) {
     using T = tile256::Tile<MTH>;
-    static bool attr_done = false;
-    static int n_cu = 256;
     constexpr int lds_bytes = PersistentLds<MTH, XDEEP>::BYTES + (EPI == EPI_QKROPE ? 4096 : 0);
     static_assert(lds_bytes <= 160 * 1024, "LDS per CU");
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)gemm256p_bf16_kernel<EPI, MTH, XDEEP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds_bytes) != hipSuccess)
-            return CODA_ERR_LAUNCH;
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-            n_cu = cus;
-        attr_done = true;
-    }
+    if (coda_ensure_dyn_lds((const void*)gemm256p_bf16_kernel<EPI, MTH, XDEEP>, lds_bytes) != CODA_OK) return CODA_ERR_LAUNCH;
+    const int n_cu = coda_device_cus();
     a.tiles_m = (a.M + T::BM - 1) / T::BM;
     a.tiles_n = (a.N + T::BN - 1) / T::BN;
     const int grid = a.tiles_m * a.tiles_n < n_cu ? a.tiles_m * a.tiles_n : n_cu;
@@ -835,17 +820,8 @@ __global__ __launch_bounds__(512, 2) void gemm256x128p_bf16_kernel(GemmArgs a) {
 
 template <int EPI>
 static int launch256x128p(GemmArgs a, hipStream_t s) {
-    static bool attr_done = false;
-    static int n_cu = 256;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)gemm256x128p_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                tile256x128::LDS_BYTES) != hipSuccess)
-            return CODA_ERR_LAUNCH;
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-            n_cu = cus;
-        attr_done = true;
-    }
+    if (coda_ensure_dyn_lds((const void*)gemm256x128p_bf16_kernel<EPI>, tile256x128::LDS_BYTES) != CODA_OK) return CODA_ERR_LAUNCH;
+    const int n_cu = coda_device_cus();
     a.tiles_m = (a.M + tile256x128::BM - 1) / tile256x128::BM;
     a.tiles_n = (a.N + tile256x128::BN - 1) / tile256x128::BN;
     const int grid = a.tiles_m * a.tiles_n < n_cu ? a.tiles_m * a.tiles_n : n_cu;
@@ -861,35 +837,25 @@ static int launch192x256px(GemmArgs a, hipStream_t s) { return launch256p<EPI, 3
 template <int EPI>
 static int launch256px(GemmArgs a, hipStream_t s) { return launch256p<EPI, 4, true>(a, s); }
 
-// 0 auto, 1 force 128x128, 2 force 256x256 (one tile per workgroup), 3 force persistent 256x256,
-// 4 force persistent 256x128, 5 force persistent 192x256 (3-stage weight ring), 6 force persistent 192x256 with the
-// 3-stage ring on the activations, 7 force persistent 256x256 with a 3-stage activation ring (160 KiB of LDS)
-static int g_gemm_variant = 0;
-static int g_gemm_wide = 1;
 #ifdef CODA_CLOCK_PROBE
+// diagnostic build only (tools/build_probe.sh): where the kernels leave their cycle stamps
 static unsigned long long* g_gemm_probe = nullptr;
 extern "C" int coda_gemm_probe(void* buf) {
     g_gemm_probe = (unsigned long long*)buf;
     return CODA_OK;
 }
 #endif
-extern "C" int coda_gemm_wide_stores(int on) {
-    g_gemm_wide = on ? 1 : 0;
-    return CODA_OK;
-}
-extern "C" int coda_gemm_select(int variant) {
-    if (variant < 0 || variant > 7) return CODA_ERR_ARG;
-    g_gemm_variant = variant;
-    return CODA_OK;
-}
 
-// -> 0: 128x128 engine, 2: 256x256 one tile per workgroup, 3: persistent 256x256, 4: persistent 256x128, 5: persistent 192x256
-static int pick_engine(const GemmArgs& a) {
+// `forced` (the engine argument of coda_gemm_bf16_ex): 0 automatic, 1 128x128, 2 256x256 (one tile per workgroup),
+// 3 persistent 256x256, 4 persistent 256x128, 5 persistent 192x256 (3-stage weight ring), 6 persistent 192x256 with the
+// 3-stage ring on the activations, 7 persistent 256x256 with a 3-stage activation ring (160 KiB of LDS).
+// -> 0: 128x128 engine, otherwise the engine number above.  The choice is a pure function of the call's arguments.
+static int pick_engine(const GemmArgs& a, int forced) {
     if (a.x_rows) return 0;
     // per-lane 32-bit DMA offsets: the operand panels of one launch must span < 4 GiB
     if ((size_t)a.M * a.ldx_bytes >= 0xffffffffull || (size_t)a.N * a.ldw_bytes >= 0xffffffffull) return 0;
-    if (g_gemm_variant == 1) return 0;
-    if (g_gemm_variant >= 2 && !(a.m_count && (g_gemm_variant == 2 || g_gemm_variant == 4))) return g_gemm_variant;
+    if (forced == 1) return 0;
+    if (forced >= 2 && !(a.m_count && (forced == 2 || forced == 4))) return forced;
     if (a.M < 256 || a.N < 128) return 0;
     // one 512-thread workgroup per CU: prefer the engine whose tile count fills whole rounds of 256 CUs
     auto fill = [](long tiles) { const long rounds = (tiles + 255) / 256; return (double)tiles / (double)(rounds * 256); };
@@ -907,20 +873,16 @@ static int pick_engine(const GemmArgs& a) {
 
 template <int EPI>
 static int launch(const GemmArgs& a, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-            return CODA_ERR_LAUNCH;
-        attr_done = true;
-    }
+    if (coda_ensure_dyn_lds((const void*)gemm_bf16_kernel<EPI>, LDS_BYTES) != CODA_OK) return CODA_ERR_LAUNCH;
     hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(256), LDS_BYTES, s, a);
     CODA_CHECK_LAUNCH("gemm_bf16");
     return CODA_OK;
 }
 
-extern "C" int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, const void* W, long long ldw,
-                              void* C, long long ldc, const void* R, long long ldr,
-                              int M, int N, int K, int epilogue, void* stream) {
+extern "C" int coda_gemm_bf16_ex(const void* X, long long ldx, const int* x_rows, const void* W, long long ldw,
+                                 void* C, long long ldc, const void* R, long long ldr,
+                                 int M, int N, int K, int epilogue, int forced_engine, int flags, void* stream) {
+    if (forced_engine < 0 || forced_engine > 7) return CODA_ERR_ARG;
     if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0 || N % 4 != 0) return CODA_ERR_SHAPE;
     if (epilogue == EPI_SWIGLU && N % 32 != 0) return CODA_ERR_SHAPE;
     if (epilogue == EPI_RESIDUAL && R == nullptr) return CODA_ERR_ARG;
@@ -936,12 +898,13 @@ extern "C" int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, c
     a.R = (const char*)R; a.ldr_bytes = ldr * 2;
     a.M = M; a.N = N; a.K = K;
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
-    a.wide = g_gemm_wide && (((uintptr_t)C | (uintptr_t)(ldc * esz)) & 15) == 0 && (!R || (((uintptr_t)R | (uintptr_t)(ldr * 2)) & 15) == 0);
+    a.wide = !(flags & CODA_GEMM_NARROW_STORES) && (((uintptr_t)C | (uintptr_t)(ldc * esz)) & 15) == 0 &&
+             (!R || (((uintptr_t)R | (uintptr_t)(ldr * 2)) & 15) == 0);
 #ifdef CODA_CLOCK_PROBE
     a.probe = g_gemm_probe;
 #endif
     hipStream_t s = (hipStream_t)stream;
-    const int engine = pick_engine(a);
+    const int engine = pick_engine(a, forced_engine);
 #define CODA_DISPATCH(fn)                                      \
     switch (epilogue) {                                        \
         case EPI_PLAIN: return fn<EPI_PLAIN>(a, s);            \
@@ -966,6 +929,12 @@ extern "C" int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, c
     }
 }
 
+extern "C" int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, const void* W, long long ldw,
+                              void* C, long long ldc, const void* R, long long ldr,
+                              int M, int N, int K, int epilogue, void* stream) {
+    return coda_gemm_bf16_ex(X, ldx, x_rows, W, ldw, C, ldc, R, ldr, M, N, K, epilogue, 0, 0, stream);
+}
+
 
 // Plain projection whose row count lives on the device (the candidate rows of the top-p / top-k path:
 // generation_utils.py:462 + modeling_coda.py:411 restricted to `logits[mask_index]`).
@@ -981,8 +950,8 @@ extern "C" int coda_gemm_bf16_counted(const void* X, long long ldx, const int* m
     a.C = (char*)C; a.ldc_bytes = ldc * 2;
     a.M = M_max; a.N = N; a.K = K;
     a.tiles_m = (M_max + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
-    a.wide = g_gemm_wide && (((uintptr_t)C | (uintptr_t)(ldc * 2)) & 15) == 0;
-    const int engine = pick_engine(a);
+    a.wide = (((uintptr_t)C | (uintptr_t)(ldc * 2)) & 15) == 0;
+    const int engine = pick_engine(a, 0);
     if (engine == 6) return launch192x256px<EPI_PLAIN>(a, (hipStream_t)stream);
     if (engine == 5) return launch192x256p<EPI_PLAIN>(a, (hipStream_t)stream);
     if (engine == 3) return launch256p<EPI_PLAIN>(a, (hipStream_t)stream);
@@ -1008,7 +977,7 @@ extern "C" int coda_qkv_proj_rope(const void* X, long long ldx, const void* W, l
     a.C = (char*)qkv; a.ldc_bytes = ld * 2;
     a.R = nullptr; a.ldr_bytes = 0;
     a.M = T; a.N = N; a.K = K;
-    a.wide = g_gemm_wide;                     // alignment checked above
+    a.wide = 1;                               // alignment checked above
     a.qn_w = (const char*)q_weight; a.kn_w = (const char*)k_weight;
     a.rope_cos = (const char*)cos; a.rope_sin = (const char*)sin;
     a.L = L; a.q_feat = n_q * 128; a.qk_feat = (n_q + n_kv) * 128; a.eps = eps;

@@ -53,15 +53,6 @@ __device__ __forceinline__ Stat stat_shfl_xor(const Stat& s, int o) {
     return r;
 }
 
-// counter-based uniform in (0,1): murmur3 finaliser over (seed, row key, vocab index)
-__device__ __forceinline__ float hash_uniform(unsigned int seed_lo, unsigned int seed_hi, unsigned int rowkey, unsigned int v) {
-    unsigned int h = v * 0x9E3779B1u ^ rowkey * 0x85EBCA77u ^ seed_lo;
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    h += seed_hi;
-    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
-    return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
-}
-
 struct LmArgs {
     const char* hidden; long long ldh_b;
     const int* src_rows; const int* dst_pos; const int* count;
@@ -165,7 +156,7 @@ __global__ __launch_bounds__(256) void lmhead_partial_kernel(LmArgs a) {
                             if (v < a.V && cand < n) {
                                 float q;
                                 if (a.noise) q = a.noise[(size_t)cand * a.V + v];
-                                else q = -__logf(hash_uniform(a.seed_lo, a.seed_hi, (unsigned)a.dst_pos[cand], (unsigned)v));
+                                else q = -__logf(coda_hash_uniform(a.seed_lo, a.seed_hi, (unsigned)a.dst_pos[cand], (unsigned)v));
                                 const float key = l[nt * 4 + r] - __logf(q);
                                 if (key > s.bkey) { s.bkey = key; s.bl = l[nt * 4 + r]; s.barg = v; }
                             }
@@ -249,33 +240,37 @@ extern "C" long long coda_lmhead_workspace_bytes(int max_rows, int V) {
     return recs * PART_FLOATS * 4 + 256;
 }
 
-extern "C" int coda_lmhead_confidence(const void* hidden, long long ld_hidden, const int* src_rows, const int* dst_pos,
-                                      const int* count, int max_rows, const void* W, long long ldw, int V, int H, int alg,
-                                      float temperature, const float* noise, unsigned long long seed, int round_conf_bf16,
-                                      float* conf, long long* x0, void* workspace, void* stream) {
+// Both entry points: argument checks, then the two launches with `part` = where the partial records go.
+static int lmhead_launch(const void* hidden, long long ld_hidden, const int* src_rows, const int* dst_pos, const int* count,
+                         int max_rows, const void* W, long long ldw, int V, int H, int alg, float temperature,
+                         const float* noise, unsigned long long seed, int round_conf_bf16, float* conf, long long* x0,
+                         void* part, void* stream) {
     if (max_rows <= 0 || V <= 0 || H <= 0 || H % BK) return CODA_ERR_SHAPE;
     if (alg < 0 || alg > 2) return CODA_ERR_ARG;
-    if (!hidden || !src_rows || !dst_pos || !count || !W || !conf || !x0 || !workspace) return CODA_ERR_ARG;
-    if (((uintptr_t)hidden | (uintptr_t)W | (uintptr_t)workspace) & 15 || (ld_hidden * 2) % 16 || (ldw * 2) % 16) return CODA_ERR_ALIGN;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)lmhead_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-            return CODA_ERR_LAUNCH;
-        attr_done = true;
-    }
+    if (!hidden || !src_rows || !dst_pos || !count || !W || !conf || !x0 || !part) return CODA_ERR_ARG;
+    if (((uintptr_t)hidden | (uintptr_t)W | (uintptr_t)part) & 15 || (ld_hidden * 2) % 16 || (ldw * 2) % 16) return CODA_ERR_ALIGN;
+    if (coda_ensure_dyn_lds((const void*)lmhead_partial_kernel, LDS_BYTES) != CODA_OK) return CODA_ERR_LAUNCH;
     LmArgs a;
     a.hidden = (const char*)hidden; a.ldh_b = ld_hidden * 2;
     a.src_rows = src_rows; a.dst_pos = dst_pos; a.count = count;
     a.W = (const char*)W; a.ldw_b = ldw * 2;
     a.V = V; a.H = H; a.alg = alg; a.temperature = temperature; a.noise = noise;
     a.seed_lo = (unsigned int)seed; a.seed_hi = (unsigned int)(seed >> 32);
-    a.part = (float*)workspace;
+    a.part = (float*)part;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(lmhead_partial_kernel, dim3(LM_GRID), dim3(256), LDS_BYTES, s, a);
     CODA_CHECK_LAUNCH("lmhead_partial");
     const int cgrid = max(1, min(2048, (max_rows + 3) / 4));
-    hipLaunchKernelGGL(lmhead_combine_kernel, dim3(cgrid), dim3(256), 0, s, (const float*)workspace, count, dst_pos, V, alg,
+    hipLaunchKernelGGL(lmhead_combine_kernel, dim3(cgrid), dim3(256), 0, s, (const float*)part, count, dst_pos, V, alg,
                        temperature > 0.f ? 1 : 0, round_conf_bf16, conf, x0);
     CODA_CHECK_LAUNCH("lmhead_combine");
     return CODA_OK;
+}
+
+extern "C" int coda_lmhead_confidence(const void* hidden, long long ld_hidden, const int* src_rows, const int* dst_pos,
+                                      const int* count, int max_rows, const void* W, long long ldw, int V, int H, int alg,
+                                      float temperature, const float* noise, unsigned long long seed, int round_conf_bf16,
+                                      float* conf, long long* x0, void* workspace, void* stream) {
+    return lmhead_launch(hidden, ld_hidden, src_rows, dst_pos, count, max_rows, W, ldw, V, H, alg, temperature, noise, seed,
+                         round_conf_bf16, conf, x0, workspace, stream);
 }

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void select_unmask_kernel(long long* __restric
                                                             const long long* __restrict__ x0, const int* __restrict__ count,
                                                             int B, int L, int lo, int hi, long long mask_id, float ratio,
                                                             int take_all, float alg_temp, const float* __restrict__ noise,
+                                                            unsigned int seed_lo, unsigned int seed_hi,
                                                             int* __restrict__ k_out, int k_fixed, float threshold,
                                                             int* __restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -129,7 +130,11 @@ __global__ __launch_bounds__(256) void select_unmask_kernel(long long* __restric
         z = red[0] + red[1] + red[2] + red[3];
         for (int i = tid; i < n; i += 256) {
             const float pr = expf(key[i] / alg_temp - mx) / z;
-            key[i] = pr / noise[(size_t)b * L + cpos[i]];
+            // Exp(1) variate of position (b, p): injected, or -log(U) from the counter hash (index 0xFFFFFFFF: the
+            // vocabulary ids the token noise uses never reach it)
+            const float q = noise ? noise[(size_t)b * L + cpos[i]]
+                                  : -__logf(coda_hash_uniform(seed_lo, seed_hi, (unsigned)(b * L + cpos[i]), 0xFFFFFFFFu));
+            key[i] = pr / q;
         }
         __syncthreads();
     }
@@ -167,20 +172,16 @@ __global__ __launch_bounds__(256) void select_unmask_kernel(long long* __restric
 
 extern "C" int coda_select_unmask(long long* x, const float* conf, const long long* x0, const int* count, int B, int L,
                                   int win_lo, int win_hi, long long mask_id, float ratio, int take_all, float alg_temp,
-                                  const float* noise, int* k_out, void* stream) {
+                                  const float* noise, unsigned long long seed, int* k_out, void* stream) {
     if (B <= 0 || L <= 0 || win_lo < 0 || win_hi > L || win_lo >= win_hi) return CODA_ERR_SHAPE;
     if (win_hi - win_lo > 16384) return CODA_ERR_SHAPE;      // LDS budget: 8 B per window position
+    if ((long long)B * L > 2147483647LL) return CODA_ERR_SHAPE;
     if (!x || !conf || !x0 || !count) return CODA_ERR_ARG;
-    if (alg_temp > 0.f && !noise) return CODA_ERR_ARG;
     const size_t lds = (size_t)(win_hi - win_lo) * 8;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)select_unmask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8) != hipSuccess)
-            return CODA_ERR_LAUNCH;
-        attr_done = true;
-    }
+    if (coda_ensure_dyn_lds((const void*)select_unmask_kernel, 16384 * 8) != CODA_OK) return CODA_ERR_LAUNCH;
     hipLaunchKernelGGL(select_unmask_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, x, conf, x0, count, B, L, win_lo,
-                       win_hi, mask_id, ratio, take_all, alg_temp, noise, k_out, -1, 0.f, (int*)nullptr);
+                       win_hi, mask_id, ratio, take_all, alg_temp, noise, (unsigned int)seed, (unsigned int)(seed >> 32), k_out,
+                       -1, 0.f, (int*)nullptr);
     CODA_CHECK_LAUNCH("select_unmask");
     return CODA_OK;
 }
@@ -192,14 +193,9 @@ extern "C" int coda_select_threshold(long long* x, const float* conf, const long
     if (win_hi - win_lo > 16384) return CODA_ERR_SHAPE;
     if (!x || !conf || !x0 || !info) return CODA_ERR_ARG;
     const size_t lds = (size_t)(win_hi - win_lo) * 8;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)select_unmask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8) != hipSuccess)
-            return CODA_ERR_LAUNCH;
-        attr_done = true;
-    }
+    if (coda_ensure_dyn_lds((const void*)select_unmask_kernel, 16384 * 8) != CODA_OK) return CODA_ERR_LAUNCH;
     hipLaunchKernelGGL(select_unmask_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, x, conf, x0, (const int*)nullptr, 1, L,
-                       win_lo, win_hi, mask_id, 0.f, 0, 0.f, (const float*)nullptr, (int*)nullptr, k, threshold, info);
+                       win_lo, win_hi, mask_id, 0.f, 0, 0.f, (const float*)nullptr, 0u, 0u, (int*)nullptr, k, threshold, info);
     CODA_CHECK_LAUNCH("select_threshold");
     return CODA_OK;
 }
@@ -207,21 +203,22 @@ extern "C" int coda_select_threshold(long long* x, const float* conf, const long
 // ------------------------------------------------------------------ `origin` transfer
 // generation_utils.py:466-483
 __global__ void origin_transfer_kernel(long long* __restrict__ x, const long long* __restrict__ x0, const int* __restrict__ dst_pos,
-                                       const int* __restrict__ count, const float* __restrict__ u, float p_transfer) {
+                                       const int* __restrict__ count, const float* __restrict__ u, unsigned int seed_lo,
+                                       unsigned int seed_hi, float p_transfer) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count[0]) return;
-    if (u[i] < p_transfer) {
-        const int at = dst_pos[i];
-        x[at] = x0[at];
-    }
+    const int at = dst_pos[i];
+    // uniform of candidate i: injected, or the counter hash of its flat position (index 0xFFFFFFFE)
+    const float ui = u ? u[i] : coda_hash_uniform(seed_lo, seed_hi, (unsigned)at, 0xFFFFFFFEu);
+    if (ui < p_transfer) x[at] = x0[at];
 }
 
 extern "C" int coda_origin_transfer(long long* x, const long long* x0, const int* dst_pos, const int* count, int max_rows,
-                                    const float* u, float p_transfer, void* stream) {
+                                    const float* u, unsigned long long seed, float p_transfer, void* stream) {
     if (max_rows <= 0) return CODA_ERR_SHAPE;
-    if (!x || !x0 || !dst_pos || !count || !u) return CODA_ERR_ARG;
+    if (!x || !x0 || !dst_pos || !count) return CODA_ERR_ARG;
     hipLaunchKernelGGL(origin_transfer_kernel, dim3((max_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, x0, dst_pos,
-                       count, u, p_transfer);
+                       count, u, (unsigned int)seed, (unsigned int)(seed >> 32), p_transfer);
     CODA_CHECK_LAUNCH("origin_transfer");
     return CODA_OK;
 }

@@ -3,7 +3,8 @@ sequence of one decoder forward / one denoise step.  PyTorch is used for device 
 streams only; all arithmetic is done by libcoda_hip.so (see include/coda_hip.h).
 
 HBM layout (bf16 unless noted; T = B*L tokens, row-major, all buffers resident for the whole
-generation - nothing is re-allocated inside the denoise loop):
+generation - nothing is allocated inside the denoise loop and no torch kernel runs in it: sampling
+noise of every kind comes from an in-kernel counter hash unless a test injects it):
   weights   embed [V,H]; per layer  wqkv [(n_q+2 n_kv)*128, H] (q|k|v rows concatenated),
             wo [H, n_q*128], wgu [2I, H] (gate/up interleaved in blocks of 16 rows so that one
             MFMA accumulator pair holds gate and up of the same feature), wd [H, I], norm vectors;
@@ -25,6 +26,21 @@ from . import _lib
 
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
+
+
+def _on_device(fn):
+    """Engine entry points run with the engine's GPU current: the C ABI launches on the given stream and reads per-device
+    facts (CU count, LDS grants) of the CURRENT device, and a process may hold engines on several GPUs."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        for t in list(args) + list(kwargs.values()):          # device check first: nothing below may touch a host tensor
+            if isinstance(t, torch.Tensor):
+                HipEngine._dev(self, t, f"a tensor passed to {fn.__name__}")
+        with torch.cuda.device(self.device):
+            return fn(self, *args, **kwargs)
+    return wrapped
 
 
 def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
@@ -120,6 +136,20 @@ class HipEngine:
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def _dev(self, t: Optional[torch.Tensor], what: str, dtype=None) -> Optional[torch.Tensor]:
+        """Every tensor whose address reaches a kernel must live on this engine's GPU: a host (or other-GPU) pointer
+        dereferenced by a kernel is a memory-access fault that takes the process down, where the reference raises a
+        Python device-mismatch error.  Checked BEFORE any launch."""
+        if t is None:
+            return None
+        if not isinstance(t, torch.Tensor) or t.device != self.device:
+            where = getattr(t, "device", type(t).__name__)
+            raise _lib.CodaHipError(f"{what} is on {where}, but the model's HIP engine is on {self.device}: move it with "
+                                    f".to('{self.device}') (there is no CPU fallback)")
+        if dtype is not None and t.dtype != dtype:
+            raise _lib.CodaHipError(f"{what} must be {dtype}, got {t.dtype}")
+        return t
+
     def _gemm(self, name, X, W, C, epi, R=None, rows=None, M=None):
         M = X.shape[0] if M is None else M
         N, K = W.shape
@@ -151,6 +181,7 @@ class HipEngine:
         return self._tail_idx
 
     @torch.no_grad()
+    @_on_device
     def forward_hidden(self, ids: torch.Tensor, need=None) -> torch.Tensor:
         """ids int64 [B,L] on the device -> final-normed hidden states bf16 [B*L, H] (engine-owned).
 
@@ -159,6 +190,11 @@ class HipEngine:
         still computed for every token, but its per-token tail (o_proj + residual, post-attention norm, MLP + residual,
         final norm: modeling_coda.py:247-253,353) runs on those rows only, compacted; all other rows of the returned
         buffer are stale.  Row-wise ops: the needed rows come out as in the full forward."""
+        self._dev(ids, "input_ids")
+        if ids.dtype != torch.int64:
+            if ids.dtype.is_floating_point or ids.dtype == torch.bool:
+                raise _lib.CodaHipError(f"input_ids must be an integer tensor, got {ids.dtype}")
+            ids = ids.to(torch.int64)            # the gather kernel reads 8-byte ids
         B, L = ids.shape
         self._ensure(B, L)
         T, s = B * L, self._stream()
@@ -208,6 +244,7 @@ class HipEngine:
         return self.hn
 
     @torch.no_grad()
+    @_on_device
     def logits(self, ids: torch.Tensor) -> torch.Tensor:
         """Unshifted logits bf16 [B, L, V] (what model(x) returns in eval mode)."""
         B, L = ids.shape
@@ -217,7 +254,9 @@ class HipEngine:
         return out.view(B, L, self.V)
 
     # ------------------------------------------------------------------ sampler steps
+    @_on_device
     def build_candidates(self, x: torch.Tensor, lo: int, hi: int):
+        self._dev(x, "x", torch.int64)
         B, L = x.shape
         _lib.call("coda_build_candidates", _ptr(x), B, L, lo, hi, self._mask_id, _ptr(self.src_rows), _ptr(self.dst_pos),
                   _ptr(self.count), self._stream())
@@ -225,11 +264,14 @@ class HipEngine:
     def set_mask_id(self, mask_id: int):
         self._mask_id = int(mask_id)
 
+    @_on_device
     def lmhead_confidence(self, max_rows: int, alg: int, temperature: float, noise, seed: int, round_conf: bool):
+        self._dev(noise, "token noise", torch.float32)
         _lib.call("coda_lmhead_confidence", _ptr(self.hn), self.H, _ptr(self.src_rows), _ptr(self.dst_pos), _ptr(self.count),
                   max_rows, _ptr(self.lm_head), self.H, self.V, self.H, alg, float(temperature), _ptr(noise), seed,
                   int(round_conf), _ptr(self.conf), _ptr(self.x0), _ptr(self.lm_ws), self._stream())
 
+    @_on_device
     def candidate_logits(self, max_rows: int) -> torch.Tensor:
         """Materialises bf16 logits [max_rows, V] of the candidate rows (top-p / top-k path)."""
         if getattr(self, "_cand_shape", None) != max_rows:
@@ -245,9 +287,14 @@ class HipEngine:
                   _ptr(out), out.stride(0), max_rows, self.V, self.H, self._stream())
         return out
 
+    @_on_device
     def confidence_from_logits(self, logits: torch.Tensor, alg: int, temperature: float, top_p, top_k, noise, seed: int,
                                round_conf: bool, use_count: bool = True, scatter: bool = True,
                                conf: Optional[torch.Tensor] = None, x0: Optional[torch.Tensor] = None):
+        self._dev(logits, "logits")
+        self._dev(noise, "token noise", torch.float32)
+        self._dev(conf, "conf", torch.float32)
+        self._dev(x0, "x0", torch.int64)
         N, V = logits.shape
         is_bf16 = 1 if logits.dtype == torch.bfloat16 else 0
         if not is_bf16 and logits.dtype != torch.float32:
@@ -258,13 +305,21 @@ class HipEngine:
                   int(round_conf), _ptr(self.conf if conf is None else conf), _ptr(self.x0 if x0 is None else x0),
                   self._stream())
 
-    def select_unmask(self, x: torch.Tensor, lo: int, hi: int, ratio: float, take_all: bool, alg_temp: float, noise):
+    @_on_device
+    def select_unmask(self, x: torch.Tensor, lo: int, hi: int, ratio: float, take_all: bool, alg_temp: float, noise,
+                      seed: int = 0):
+        """noise None with alg_temp > 0: the selection race's Exp(1) variates come from the in-kernel counter hash of
+        ``seed`` (no torch RNG launch, no [B, L] noise tensor per step)."""
+        self._dev(x, "x", torch.int64)
+        self._dev(noise, "selection noise", torch.float32)
         B, L = x.shape
         _lib.call("coda_select_unmask", _ptr(x), _ptr(self.conf), _ptr(self.x0), _ptr(self.count), B, L, lo, hi, self._mask_id,
-                  float(ratio), int(take_all), float(alg_temp), _ptr(noise), _ptr(self.k_out), self._stream())
+                  float(ratio), int(take_all), float(alg_temp), _ptr(noise), int(seed), _ptr(self.k_out), self._stream())
 
+    @_on_device
     def select_threshold(self, x: torch.Tensor, lo: int, hi: int, k: int, threshold: float):
         """One sequence; returns (revealed, held_back) - the alg's one host read per step (the loop length depends on it)."""
+        self._dev(x, "x", torch.int64)
         B, L = x.shape
         if B != 1:
             raise _lib.CodaHipError("confidence_threshold works on one sequence")
@@ -275,6 +330,10 @@ class HipEngine:
         revealed, held = self._thr_info.tolist()
         return revealed, held
 
-    def origin_transfer(self, x: torch.Tensor, max_rows: int, u: torch.Tensor, p_transfer: float):
+    @_on_device
+    def origin_transfer(self, x: torch.Tensor, max_rows: int, u: Optional[torch.Tensor], p_transfer: float, seed: int = 0):
+        """u None: the uniforms come from the in-kernel counter hash of ``seed``."""
+        self._dev(x, "x", torch.int64)
+        self._dev(u, "origin uniforms", torch.float32)
         _lib.call("coda_origin_transfer", _ptr(x), _ptr(self.x0), _ptr(self.dst_pos), _ptr(self.count), max_rows, _ptr(u),
-                  float(p_transfer), self._stream())
+                  int(seed), float(p_transfer), self._stream())

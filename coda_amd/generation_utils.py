@@ -8,7 +8,7 @@ device-resident: no host sync per step, no [B,L,V] logits unless a hook asks for
 Build-defined additions (all optional, defaults reproduce the reference):
   block_length   windowed unmasking; None or == max_new_tokens -> reference
   round_conf_to  "bf16" rounds confidences to bf16 as the reference's bf16 arithmetic does (F5)
-  noise_source   object supplying sampling noise (tests inject recorded noise; default: device RNG)
+  noise_source   object supplying sampling noise (tests inject recorded noise; default: in-kernel counter hash)
 """
 from __future__ import annotations
 
@@ -75,12 +75,13 @@ class DLMGenerationConfig(GenerationConfig):
 
 # ---------------------------------------------------------------------------------- noise
 class DeviceNoise:
-    """Default sampling noise.  Token noise (temperature > 0) is generated inside the lm-head
-    kernel from a counter hash keyed by this seed; selection / origin noise comes from torch's
-    device generator.  ``torch.manual_seed`` therefore makes a run reproducible."""
+    """Default sampling noise.  Nothing is drawn by torch inside the loop: token noise (temperature > 0), the selection
+    race (alg_temp > 0) and the ``origin`` uniforms are all generated INSIDE the kernels from a counter hash keyed by
+    (step seed, flat position, index) - coda_hash_uniform in csrc/coda_common.h.  The run seed is one draw from torch's
+    CPU generator per generate, so ``torch.manual_seed`` makes a run reproducible.  (Same-seed equality with the
+    reference's own RNG stream is impossible across devices and is not claimed: SURVEY.md F6.)"""
 
-    def __init__(self, device):
-        self.device = device
+    def __init__(self, device=None):
         self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
 
     def token_noise(self, step, cap_rows, V, picked=None):
@@ -90,10 +91,20 @@ class DeviceNoise:
         return (self.seed + 0x9E3779B97F4A7C15 * (step + 1)) & 0xFFFFFFFFFFFFFFFF
 
     def select_noise(self, step, B, L):
-        return torch.empty(B, L, device=self.device, dtype=torch.float32).exponential_(1)
+        return None
 
     def origin_uniform(self, step, cap_rows):
-        return torch.rand(cap_rows, device=self.device, dtype=torch.float32)
+        return None
+
+
+@dataclass
+class _Call:
+    """Per-call options that are not generation_config fields (kept off the model object: two generate calls must
+    not see each other's state)."""
+    threshold: float = 0.9              # serving sampler's keyword (serving/dream/model/generation_utils.py:357)
+    debug_trace: Optional[list] = None  # tests: receives per-step device confidences
+    prompt_has_mask: bool = False
+    noise_source: object = None
 
 
 def fp32_schedule(steps_per_block: int, eps: float):
@@ -174,15 +185,14 @@ class DLMGenerationMixin:
         tokens_hook = kwargs.pop("generation_tokens_hook_func", None)
         logits_hook = kwargs.pop("generation_logits_hook_func", None)
         attention_mask = kwargs.pop("attention_mask", None)
-        noise_source = kwargs.pop("noise_source", None)
-        # the serving sampler's extra keyword (serving/dream/model/generation_utils.py:357), used by alg="confidence_threshold"
-        self._threshold = kwargs.pop("threshold", 0.9)
-        self._debug_trace = kwargs.pop("debug_trace", None)     # list: receives per-step device confidences (tests)
+        call = _Call(noise_source=kwargs.pop("noise_source", None), threshold=kwargs.pop("threshold", 0.9),
+                     debug_trace=kwargs.pop("debug_trace", None))
         had_max_length_kwarg = kwargs.get("max_length") is not None
         generation_config = self._prepare_generation_config(generation_config, **kwargs)
 
         assert inputs is not None
         input_ids = inputs
+        self._prepare_special_tokens(generation_config)
         P = input_ids.shape[-1]
         has_default_max_length = (not had_max_length_kwarg) and generation_config.max_length is not None
         generation_config = self._prepare_generated_length(generation_config, has_default_max_length, P)
@@ -193,32 +203,61 @@ class DLMGenerationMixin:
                 "You are calling .generate() with the `input_ids` being on a device type different than your model's"
                 f" device. `input_ids` is on {input_ids.device.type}, whereas the model is on {self.device.type}.",
                 UserWarning)
-        self._prompt_has_pad = None
-        if generation_config.pad_token_id is not None and attention_mask is None:
-            # the reference's one pre-loop host sync (generation_utils.py:386-395); the mask-in-prompt probe rides on it
-            probe = torch.stack([(input_ids == generation_config.pad_token_id).any(),
-                                 (input_ids == generation_config.mask_token_id).any()]).tolist()
-            if probe[0]:
-                warnings.warn(
-                    "Padding was detected but no attention mask is passed here. For correct generation results, please "
-                    "set `attention_mask` when batch-padding inputs.", UserWarning)
-            self._prompt_has_mask = bool(probe[1])
-        else:
-            self._prompt_has_mask = bool((input_ids == generation_config.mask_token_id).any().item())
+        if input_ids.device != self.device:
+            # the reference fails inside embed_tokens with a Python device-mismatch error; here the ids' address would go
+            # straight into a kernel, so the same condition must be an exception BEFORE any launch, never a GPU fault
+            raise _lib.CodaHipError(
+                f"input_ids is on {input_ids.device}, but the model is on {self.device}: call input_ids.to('{self.device}') "
+                "first (coda_amd has no CPU path and does not move inputs silently)")
+        if input_ids.dtype.is_floating_point or input_ids.dtype == torch.bool:
+            raise _lib.CodaHipError(f"input_ids must be an integer tensor, got {input_ids.dtype}")
+        # One host read before the loop (the reference has it too: torch.any(input_ids == pad), generation_utils.py:386-390).
+        # The mask-in-prompt probe and the id range check ride on it: nn.Embedding raises on ids outside [0, V) in the
+        # reference, while a gather kernel cannot (it would read another row, or fault).
+        pad = generation_config.pad_token_id
+        if generation_config.mask_token_id is None:
+            raise ValueError("mask_token_id is not set (neither in generation_config nor in the model config)")
+        probe = torch.stack([(input_ids == pad).any() if pad is not None else input_ids.new_zeros((), dtype=torch.bool),
+                             (input_ids == generation_config.mask_token_id).any(),
+                             (input_ids < 0).any() | (input_ids >= self.config.vocab_size).any()]).tolist()
+        if probe[2]:
+            raise IndexError(f"index out of range in self: input_ids must lie in [0, {self.config.vocab_size})")
+        if not 0 <= int(generation_config.mask_token_id) < self.config.vocab_size:
+            raise IndexError(f"mask_token_id {generation_config.mask_token_id} is outside the vocabulary [0, {self.config.vocab_size})")
+        if probe[0] and attention_mask is None:
+            warnings.warn(
+                "Padding was detected but no attention mask is passed here. For correct generation results, please "
+                "set `attention_mask` when batch-padding inputs.", UserWarning)
+        call.prompt_has_mask = bool(probe[1])
 
         input_ids, attention_mask = self._expand_inputs_for_generation(
             generation_config.num_return_sequences, input_ids, attention_mask)
-        return self._sample(input_ids, attention_mask, generation_config, tokens_hook, logits_hook, noise_source)
+        return self._sample(input_ids, attention_mask, generation_config, tokens_hook, logits_hook, call)
+
+    def _prepare_special_tokens(self, generation_config):
+        """generation_utils.py:279-334.  The reference turns the four ids into tensors kept in private attributes that
+        nothing on this path reads; what is observable is the pad <- eos defaulting (:316-325) and its warning."""
+        eos = generation_config.eos_token_id
+        if isinstance(eos, torch.Tensor):
+            eos = eos.reshape(-1).tolist()
+        if generation_config.pad_token_id is None and eos is not None:
+            first = eos[0] if isinstance(eos, (list, tuple)) else eos
+            generation_config.pad_token_id = int(first)
+            logger.warning(f"Setting `pad_token_id` to `eos_token_id`:{generation_config.pad_token_id} for open-end generation.")
 
     # ------------------------------------------------------------------------------ the denoise loop
-    def _sample(self, input_ids, attention_mask, generation_config, tokens_hook, logits_hook, noise_source=None):
+    def _sample(self, input_ids, attention_mask, generation_config, tokens_hook, logits_hook, call=None):
         """Device-resident restatement of the reference loop (generation_utils.py:412-552).
         ``attention_mask`` is accepted and has no effect, as in the reference."""
         gc = generation_config
+        call = call if call is not None else _Call()
+        noise_source = call.noise_source
         alg, alg_temp, temperature = gc.alg, gc.alg_temp, float(gc.temperature or 0.0)
         if alg not in ("origin", "maskgit_plus", "topk_margin", "entropy", "confidence_threshold"):
             raise RuntimeError(f"Unknown alg: {alg}")
         eng = self.hip_engine()
+        if input_ids.device != eng.device:
+            raise _lib.CodaHipError(f"input_ids is on {input_ids.device}, but the model's HIP engine is on {eng.device}")
         eng.set_mask_id(gc.mask_token_id)
         want_history = bool(gc.return_dict_in_generate and gc.output_history)
         histories = [] if want_history else None
@@ -250,7 +289,7 @@ class DLMGenerationMixin:
             assert n_masks % steps == 0, "mask_index.sum() must be divisible by steps"
             assert B == 1, "batch size must be 1"
             quota, held_back = n_masks // steps, 0
-            threshold = float(self._threshold)
+            threshold = float(call.threshold)
             if round_conf:                                 # bf16 confidences compare against the bf16 threshold
                 threshold = float(torch.tensor(threshold, dtype=torch.bfloat16))
         i = -1
@@ -259,7 +298,7 @@ class DLMGenerationMixin:
             blk, j = divmod(min(i, gc.steps - 1), steps_b)
             if n_blocks == 1:
                 # reference mode: every masked position of the row is a candidate (prompt included if it holds masks)
-                lo, hi = (0 if self._prompt_has_mask or tokens_hook is not None else P), L
+                lo, hi = (0 if call.prompt_has_mask or tokens_hook is not None else P), L
             else:
                 lo, hi = P + blk * bl, P + (blk + 1) * bl
             cap = B * (hi - lo)
@@ -272,10 +311,10 @@ class DLMGenerationMixin:
             u = picked = None
             if alg == "origin":
                 p_transfer = 1.0 if last else ratios[j]
-                u = noise.origin_uniform(i, cap)
-                picked = u < p_transfer
+                u = noise.origin_uniform(i, cap)               # None: generated in the transfer kernel from the step seed
+                picked = (u < p_transfer) if u is not None else None
             tok_noise = noise.token_noise(i, cap, eng.V, picked) if temperature > 0 else None
-            seed = noise.step_seed(i) if (temperature > 0 and tok_noise is None) else 0
+            seed = noise.step_seed(i)
             logits = None
             if fused:
                 eng.lmhead_confidence(cap, alg_id, temperature, tok_noise, seed, round_conf)
@@ -292,11 +331,11 @@ class DLMGenerationMixin:
                     rows = rows.float()
                 eng.confidence_from_logits(rows.contiguous(), alg_id, temperature, top_p, top_k, tok_noise, seed, round_conf)
 
-            if getattr(self, "_debug_trace", None) is not None:
-                self._debug_trace.append(dict(step=i, conf=eng.conf.clone(), x0=eng.x0.clone(), count=eng.count.clone(),
+            if call.debug_trace is not None:
+                call.debug_trace.append(dict(step=i, conf=eng.conf.clone(), x0=eng.x0.clone(), count=eng.count.clone(),
                                               dst=eng.dst_pos.clone(), lo=lo, hi=hi))
             if alg == "origin":
-                eng.origin_transfer(x, cap, u, p_transfer)
+                eng.origin_transfer(x, cap, u, p_transfer, seed)
             elif alg == "confidence_threshold":
                 current = quota + held_back
                 _, held = eng.select_threshold(x, lo, hi, current, threshold)
@@ -306,7 +345,7 @@ class DLMGenerationMixin:
                     steps += 1
             else:
                 sel_noise = noise.select_noise(i, B, L) if a_temp > 0 else None
-                eng.select_unmask(x, lo, hi, ratios[j], last, a_temp, sel_noise)
+                eng.select_unmask(x, lo, hi, ratios[j], last, a_temp, sel_noise, seed)
 
             if tokens_hook is not None:
                 x = tokens_hook(i, x, logits)

@@ -8,7 +8,10 @@
  *   - every call only enqueues work on `stream` and returns (no sync, no allocation);
  *   - return value: 0 = ok, <0 = error (CODA_ERR_*); nothing is launched on error;
  *   - bf16 tensors are raw uint16 storage, row-major, leading dimensions in ELEMENTS;
- *   - no ownership transfer: all buffers (including workspaces) belong to the caller.
+ *   - no ownership transfer: all buffers (including workspaces) belong to the caller;
+ *   - no tunable global state: a call's result and kernel choice depend on its arguments only.  The library keeps,
+ *     per device, the CU count and which kernels already had their dynamic-LDS limit raised (read-once facts), and a
+ *     thread-local last-error string.  Calls must be made with the stream's device current (hipSetDevice).
  */
 #ifndef CODA_HIP_H
 #define CODA_HIP_H
@@ -17,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CODA_ABI_VERSION 1
+#define CODA_ABI_VERSION 2
 
 #define CODA_OK 0
 #define CODA_ERR_SHAPE (-1)  /* unsupported / inconsistent dimensions */
@@ -57,12 +60,16 @@ int coda_rmsnorm(const void* x, long long ldx, const void* weight, void* out, lo
 int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, const void* W, long long ldw, void* C,
                    long long ldc, const void* R, long long ldr, int M, int N, int K, int epilogue, void* stream);
 
-/* Tuning/diagnostic knob: which tile engine coda_gemm_bf16 uses (0 = automatic choice by shape,
- * 1 = 128x128 engine, 2 = 256x256 engine with one tile per workgroup, 3 = persistent 256x256 engine, 4 = persistent 256x128 engine).  Results are identical up to fp32 summation order. */
-int coda_gemm_select(int variant);
-/* Diagnostic knob (A/B and tests): 0 = interior tiles store 8-byte pieces per lane, 1 (default) = 16-byte pieces after a
- * v_permlane16_swap exchange (half as many store instructions; same bytes, same results). */
-int coda_gemm_wide_stores(int on);
+/* coda_gemm_bf16 with the tile engine and store width chosen by the CALLER (A/B benches and the per-engine exactness
+ * tests; the product path calls coda_gemm_bf16 = engine 0, flags 0).  engine: 0 = automatic choice by shape,
+ * 1 = 128x128, 2 = 256x256 one tile per workgroup, 3 = persistent 256x256, 4 = persistent 256x128, 5 / 6 = persistent
+ * 192x256 with the 3-stage ring on the weights / the activations, 7 = persistent 256x256 with a 3-stage activation
+ * ring.  flags: CODA_GEMM_NARROW_STORES = interior tiles store 8-byte pieces per lane instead of 16-byte pieces after
+ * a v_permlane16_swap exchange.  Results are identical up to fp32 summation order. */
+#define CODA_GEMM_NARROW_STORES 1
+int coda_gemm_bf16_ex(const void* X, long long ldx, const int* x_rows, const void* W, long long ldw, void* C,
+                      long long ldc, const void* R, long long ldr, int M, int N, int K, int epilogue, int engine,
+                      int flags, void* stream);
 
 /* q_norm / k_norm + rotary embedding, in place on the fused QKV activation.
  * Replaces modeling_coda.py:128-148 and modeling_utils.py:70-101.
@@ -104,6 +111,11 @@ int coda_scatter_rows(const void* src, long long ld_src, const int* rows, int n,
  * consumes, modeling_coda.py:153-154).  T = B*L, head_dim 128, n_q % n_kv == 0. */
 int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void* out, long long ld_out, int B, int L, int n_q,
                               int n_kv, float scale, void* stream);
+/* Same, with the work split chosen by the caller (A/B benches, bit-identity tests): pair_mode -1 = automatic,
+ * 0 = one query head per workgroup, 1 = the two query heads of a GQA pair share one K/V stream; qsplit 0 = automatic,
+ * > 0 = workgroups per (batch, head).  Results do not depend on either. */
+int coda_flash_attn_noncausal_ex(const void* qkv, long long ld_qkv, void* out, long long ld_out, int B, int L, int n_q,
+                                 int n_kv, float scale, int pair_mode, int qsplit, void* stream);
 
 /* Candidate list for one denoise step.  Replaces `mask_index = x == mask_token_id`,
  * the shift `cat(logits[:, :1], logits[:, :-1])` and the boolean gather `logits[mask_index]`
@@ -121,7 +133,8 @@ int coda_build_candidates(const long long* x, int B, int L, int win_lo, int win_
  * x0 = argmax (first index) or, if temperature > 0, argmax(logit - log(noise)) with
  * noise fp32 [max_rows, V] ~ Exp(1) (the exponential race of Categorical.sample());
  * noise == NULL with temperature > 0: Exp(1) variates come from an in-kernel counter hash of
- * (seed, dst_pos[i], vocab index) - see coda_amd/rng.py for the host restatement;
+ * (seed, dst_pos[i], vocab index) - coda_hash_uniform in coda_amd/csrc/coda_common.h, restated on the host by
+ * tests/test_hip_kernels.py::hash_uniform_host;
  * confidence per `alg`.  Outputs are written at conf[dst_pos[i]], x0[dst_pos[i]].
  * workspace: coda_lmhead_workspace_bytes(max_rows, V) bytes.  max_rows bounds the grid; rows
  * beyond count[0] do no work.  H % 64 == 0, V % 4 == 0. */
@@ -145,11 +158,12 @@ int coda_confidence_from_logits(const void* logits, long long ld, int is_bf16, i
  * reference does; take_all != 0 on the last step of a schedule: k = trunc(count/B)).
  * Per row b, among masked positions in [win_lo, win_hi): alg_temp == 0 -> the k largest conf
  * (ties: lowest index); alg_temp > 0 -> the k largest softmax(conf/alg_temp)/noise with
- * noise fp32 [B,L] ~ Exp(1) (== torch.multinomial without replacement).  Writes x[b,p] = x0[b,p]
- * in place for the selected p.  k_out (nullable) receives k. */
+ * noise fp32 [B,L] ~ Exp(1) (== torch.multinomial without replacement); noise == NULL: the Exp(1) variate of
+ * position (b, p) is -log(coda_hash_uniform(seed, b*L + p, 0xFFFFFFFF)), generated in the kernel (no RNG launch,
+ * no noise tensor).  Writes x[b,p] = x0[b,p] in place for the selected p.  k_out (nullable) receives k. */
 int coda_select_unmask(long long* x, const float* conf, const long long* x0, const int* count, int B, int L,
                        int win_lo, int win_hi, long long mask_id, float ratio, int take_all, float alg_temp,
-                       const float* noise, int* k_out, void* stream);
+                       const float* noise, unsigned long long seed, int* k_out, void* stream);
 
 /* `confidence_threshold` selection for ONE sequence.  Replaces the serving sampler's
  * serving/dream/model/generation_utils.py:442-465: among the masked positions of x[0, win_lo:win_hi) take
@@ -160,9 +174,10 @@ int coda_select_threshold(long long* x, const float* conf, const long long* x0, 
                           long long mask_id, int k, float threshold, int* info, void* stream);
 
 /* `origin` algorithm transfer (generation_utils.py:466-483): every candidate i < count[0] with
- * u[i] < p_transfer takes x[dst_pos[i]] = x0[dst_pos[i]].  u fp32 [count] uniform(0,1). */
+ * u[i] < p_transfer takes x[dst_pos[i]] = x0[dst_pos[i]].  u fp32 [count] uniform(0,1); u == NULL: the uniform of
+ * candidate i is coda_hash_uniform(seed, dst_pos[i], 0xFFFFFFFE), generated in the kernel. */
 int coda_origin_transfer(long long* x, const long long* x0, const int* dst_pos, const int* count, int max_rows,
-                         const float* u, float p_transfer, void* stream);
+                         const float* u, unsigned long long seed, float p_transfer, void* stream);
 
 #ifdef __cplusplus
 }

@@ -5,9 +5,9 @@ from the HIP path's x at every step), so one near-tie cannot cascade.  Per step 
 
   tokens       x0 of every candidate equals the oracle's, except where the oracle's own winner /
                runner-up distance is inside the declared near-tie band: greedy - top-2 logits within
-               BAND_TOK (two bf16 ulps, relative); sampling - the two best race keys p/q within
-               e^u - 1, u = what two bf16 ulps of the row's largest logit become after the division by
-               the temperature (token_band()).
+               BAND_TOK (two bf16 ulps, relative); sampling - the relative gap of the two best race keys
+               p/q at most 1 - e^-u, u = two bf16 ulps of the row's largest PRE-division logit, amplified
+               by 1/T, plus two ulps of the bf16 quotient (logit_band(), token_band()).
   confidence   for candidates whose token agrees, |conf_hip - conf_oracle| <= conf_tolerance(...):
                what a two-ulp change of the row's largest bf16 logit does to the confidence, plus
                the oracle's own bf16 rounding of the confidence.  (Logits are bf16 in the reference;
@@ -30,21 +30,32 @@ def bf16_ulp(x: torch.Tensor) -> torch.Tensor:
     return torch.exp2(torch.floor(torch.log2(x.abs().clamp_min(1e-30))) - 7)
 
 
+def logit_band(absmax: torch.Tensor, temperature: float) -> torch.Tensor:
+    """u = bound on how far a DIFFERENCE of two softmax inputs of a row may sit from the oracle's: every bf16 logit of
+    the HIP forward may differ from the oracle's by one bf16 ulp of the row's largest logit (two ulps on a difference).
+    ``absmax`` is the oracle's largest |softmax input|, i.e. AFTER its division by the temperature (ref_cpu.sample_tokens
+    diag), so the logit that carried the ulp had magnitude absmax * T: its ulp is amplified by 1 / T once, and the bf16
+    quotient is rounded again at its own magnitude."""
+    if temperature <= 0:
+        return bf16_ulp(absmax) * 2.0
+    return bf16_ulp(absmax * temperature) * 2.0 / temperature + bf16_ulp(absmax) * 2.0
+
+
 def token_band(absmax: torch.Tensor, temperature: float) -> torch.Tensor:
+    """Largest oracle-side decision margin at which the HIP path may pick the runner-up instead.  Greedy: the margin is
+    (l1 - l2) / |l1| and the band two bf16 ulps, relative.  Sampling: the margin is the relative gap 1 - key2 / key1 of the
+    two best race keys p / q; moving the two logits by u in total scales key2 / key1 by at most e^u, so the order can
+    flip only if 1 - gap >= e^-u, i.e. gap <= 1 - e^-u (always < 1: a gap of 1 is never excused)."""
     if temperature <= 0:
         return torch.full_like(absmax, BAND_TOK)
-    u = bf16_ulp(absmax) * 2.0 / temperature + bf16_ulp(absmax) * 2.0
-    return torch.expm1(u)
+    return -torch.expm1(-logit_band(absmax, temperature))
 
 
 def conf_tolerance(conf_o: torch.Tensor, absmax: torch.Tensor, pmax: torch.Tensor, alg: str, temperature: float) -> torch.Tensor:
-    """|conf_hip - conf_oracle| bound: a two-ulp move of the row's largest bf16 logit (before and, if sampling,
-    after the bf16 division by the temperature) scales probabilities by e^u; the oracle additionally rounds
-    probabilities (and their difference / entropy sum) to bf16."""
-    u = bf16_ulp(absmax) * 2.0
-    if temperature > 0:
-        u = u / temperature + bf16_ulp(absmax) * 2.0
-    grow = torch.expm1(u)
+    """|conf_hip - conf_oracle| bound: moving every softmax input by at most u / 2 scales every probability by a factor
+    in [e^-u, e^u] (logit_band); the oracle additionally rounds probabilities (and their difference / entropy sum) to
+    bf16.  entropy: |d sum p log p| <= (e^u - 1) * (|H| + 1) to first order in the probability ratios."""
+    grow = torch.expm1(logit_band(absmax, temperature))
     if alg == "entropy":
         base = conf_o.abs() + 1.0
     elif alg == "topk_margin":
@@ -52,6 +63,14 @@ def conf_tolerance(conf_o: torch.Tensor, absmax: torch.Tensor, pmax: torch.Tenso
     else:
         base = conf_o.abs()
     return (grow + 2.0 ** -7) * base + 1e-4
+
+
+def describe(st) -> str:
+    """One line for test output: the error is printed next to the tolerance it was held against."""
+    return (f"{st['exact_steps']}/{st['steps']} steps identical to the bf16 oracle; {st['candidates']} candidate rows, "
+            f"{st['band_tok']} tokens inside the declared band (largest band used {st['max_band']:.3g}); "
+            f"max |conf err| {st['max_conf_err']:.4g}, worst err/tol {st['max_conf_err_over_tol']:.2f} (tol there {st['tol_at_max']:.3g}); "
+            f"{len(st['violations'])} violations")
 
 
 def teacher_forced(sd, d, ids, hip_hist, hip_trace, noise_log=None, states=None, step_indices=None, **kw):
@@ -66,7 +85,7 @@ def teacher_forced(sd, d, ids, hip_hist, hip_trace, noise_log=None, states=None,
     tr = ref_cpu.diffusion_generate(sd, d, ids, force_states=states, trace=True, noise=noise, step_indices=step_indices, **kw)
     sel_noise = {s: t for k_, s, t in (noise_log or []) if k_ == "select"}
     st = dict(steps=len(hip_hist), exact_steps=0, candidates=0, band_tok=0, conf_checked=0, max_conf_err=0.0,
-              max_conf_err_over_tol=0.0, violations=[])
+              max_conf_err_over_tol=0.0, tol_at_max=0.0, max_band=0.0, violations=[])
     B, L = x_init.shape
     if alg == "confidence_threshold":
         # the serving sampler's bookkeeping (serving/dream/model/generation_utils.py:416-465), replayed on the HIP
@@ -95,7 +114,7 @@ def teacher_forced(sd, d, ids, hip_hist, hip_trace, noise_log=None, states=None,
             picked = x0_o != d.mask_id                      # the oracle only samples the transferred rows
             gap = tr.gap[i]
             tok_bad = picked & (x0_h != x0_o)
-            band = torch.full_like(gap, BAND_TOK) if temperature <= 0 else torch.full_like(gap, math.expm1(4 * 0.125 / temperature))
+            band = torch.full_like(gap, BAND_TOK) if temperature <= 0 else torch.full_like(gap, -math.expm1(-4 * 0.125 / temperature))
             st["band_tok"] += int((tok_bad & (gap <= band)).sum())
             if (tok_bad & (gap > band)).any():
                 st["violations"].append((i, f"token differs outside band, gaps {gap[tok_bad].tolist()}"))
@@ -119,7 +138,11 @@ def teacher_forced(sd, d, ids, hip_hist, hip_trace, noise_log=None, states=None,
         if ok.any():
             st["conf_checked"] += int(ok.sum())
             st["max_conf_err"] = max(st["max_conf_err"], float(err[ok].max()))
-            st["max_conf_err_over_tol"] = max(st["max_conf_err_over_tol"], float((err[ok] / tol[ok]).max()))
+            ratio = (err / tol).masked_fill(~ok, -1.0)
+            if float(ratio.max()) > st["max_conf_err_over_tol"]:
+                st["max_conf_err_over_tol"] = float(ratio.max())
+                st["tol_at_max"] = float(tol[int(ratio.argmax())])
+            st["max_band"] = max(st["max_band"], float(band.max()))
             if (err[ok] > tol[ok]).any():
                 j = int((err / tol).masked_fill(~ok, 0).argmax())
                 st["violations"].append((i, f"confidence outside tolerance: hip {conf_h[j]:.6g} oracle {conf_o[j]:.6g} tol {tol[j]:.3g}"))

@@ -71,8 +71,9 @@ def test_forward_logits_vs_oracle(small, mid):
         scale = ref.std().item()
         print(f"forward L2: logits std {scale:.3f} max err {err.max():.4f} mean err {err.mean():.5f}")
         # bf16 tolerance: accumulation-order differences through the layers; stated relative to the logit scale
-        assert err.mean().item() < 0.02 * scale
-        assert err.max().item() < 0.25 * scale
+        # observed on MI355X: mean 0.4 %, max 2.6 % of the logit std; asserted at 3x that
+        assert err.mean().item() < 0.012 * scale
+        assert err.max().item() < 0.08 * scale
         agree = (out.float().cpu().argmax(-1) == ref.argmax(-1)).float().mean().item()
         assert agree > 0.97, agree
 
@@ -80,7 +81,7 @@ def test_forward_logits_vs_oracle(small, mid):
 @pytest.mark.parametrize("alg", ["entropy", "maskgit_plus", "topk_margin"])
 @pytest.mark.parametrize("block_length", [None, 8])
 def test_greedy_generate_teacher_forced(small, alg, block_length):
-    from parity import teacher_forced
+    from parity import describe, teacher_forced
     d, sd, m = small
     g = torch.Generator().manual_seed(3)
     ids = torch.randint(0, d.pad_id, (4, 24), generator=g)
@@ -94,10 +95,7 @@ def test_greedy_generate_teacher_forced(small, alg, block_length):
     assert (out.sequences[:, :24].cpu() == ids).all()
     assert (out.sequences != d.mask_id).all()
     stats, tr = teacher_forced(sd, d, ids, hist, trace, block_length=block_length, **kw)
-    print(f"teacher-forced {alg} bl={block_length}: {stats['exact_steps']}/16 steps identical to the bf16 oracle; "
-          f"{stats['candidates']} candidate rows, {stats['band_tok']} tokens in the declared logit tie band, "
-          f"max |conf err| {stats['max_conf_err']:.4g} = {stats['max_conf_err_over_tol']:.2f} x tolerance, "
-          f"{len(stats['violations'])} violations")
+    print(f"teacher-forced {alg} bl={block_length}: {describe(stats)}")
     assert not stats["violations"], stats["violations"][:5]
 
 
@@ -259,13 +257,11 @@ def test_stochastic_with_injected_noise(small, cfg):
     trace = []
     out = m.diffusion_generate(ids.to(DEV), mask_token_id=d.mask_id, noise_source=Replay(noise.log, d.vocab),
                                return_dict_in_generate=True, output_history=True, debug_trace=trace, **kw)
-    from parity import teacher_forced
+    from parity import describe, teacher_forced
     hist = [h.cpu() for h in out.history]
     stats, tr = teacher_forced(sd, d, ids, hist, trace, noise_log=noise.log, **kw)
     rate = (out.sequences.cpu() == ref.sequences).float().mean().item()
-    print(f"stochastic {cfg}: free-running token match {rate:.3f}; teacher-forced {stats['exact_steps']}/8 steps identical, "
-          f"{stats['band_tok']} tok-band, max conf err {stats['max_conf_err']:.4g} = {stats['max_conf_err_over_tol']:.2f} x tol, "
-          f"{len(stats['violations'])} violations")
+    print(f"stochastic {cfg}: free-running token match {rate:.3f}; teacher-forced {describe(stats)}")
     assert not stats["violations"], stats["violations"][:5]
 
 
@@ -289,7 +285,7 @@ def test_lm_eval_adapter_left_padded(small, temperature):
     and cut to max_prompt_len, attention_mask passed, top_p = 0.9 with T = 0 (deterministic) and the eval scripts'
     T = 0.1 (noise replayed from the oracle)."""
     from coda_amd.lm_eval_adapter import DiffLLMAdapter
-    from parity import teacher_forced
+    from parity import describe, teacher_forced
     d, sd, m = small
     g = torch.Generator().manual_seed(77)
     prompts = [torch.randint(0, d.pad_id, (n,), generator=g).tolist() for n in (9, 4, 12, 1)]
@@ -309,8 +305,7 @@ def test_lm_eval_adapter_left_padded(small, temperature):
     out = m.diffusion_generate(ids, attention_mask=attn, debug_trace=trace, **extra, **gk)
     assert (out.sequences[:, :10] == ids).all() and (out.sequences != d.mask_id).all()
     stats, _ = teacher_forced(sd, d, ids.cpu(), [h.cpu() for h in out.history], trace, noise_log=log, **kw)
-    print(f"lm-eval shape T={temperature}: {stats['exact_steps']}/16 steps identical, {stats['band_tok']} tok-band, "
-          f"max conf err {stats['max_conf_err']:.4g}, {len(stats['violations'])} violations")
+    print(f"lm-eval shape T={temperature}: {describe(stats)}")
     assert not stats["violations"], stats["violations"][:5]
     if temperature == 0:
         resp = a.generate_batch_ids(prompts)
@@ -330,7 +325,7 @@ def test_confidence_threshold_serving_alg(small, cfg):
     """the serving sampler's confidence_threshold alg (serving/dream/model/generation_utils.py:416-465),
     one sequence, data-dependent step count; teacher-forced against the oracle, bookkeeping replayed on HIP confidences."""
     from coda_amd.serving import SamplerService
-    from parity import teacher_forced
+    from parity import describe, teacher_forced
     d, sd, m = small
     g = torch.Generator().manual_seed(52)
     ids = torch.randint(0, d.pad_id, (1, 7), generator=g)
@@ -348,8 +343,7 @@ def test_confidence_threshold_serving_alg(small, cfg):
     hist = [h.cpu() for h in out.history]
     assert (out.sequences != d.mask_id).all() and len(hist) >= cfg["steps"] and len(trace) == len(hist)
     stats, _ = teacher_forced(sd, d, ids, hist, trace, noise_log=log, **kw)
-    print(f"confidence_threshold {cfg}: {len(hist)} steps used; {stats['exact_steps']} identical, {stats['band_tok']} tok-band, "
-          f"max conf err {stats['max_conf_err']:.4g} = {stats['max_conf_err_over_tol']:.2f} x tol, {len(stats['violations'])} violations")
+    print(f"confidence_threshold {cfg}: {len(hist)} steps used; {describe(stats)}")
     assert not stats["violations"], stats["violations"][:5]
     if cfg["temperature"] == 0:
         # the serving mirror returns the same completion, mask/pad ids dropped

@@ -111,7 +111,7 @@ def test_c2_last_layer_compact_tail_equals_full_forward(full):
 
 
 def test_c2_teacher_forced_sample_vs_cpu_oracle(full):
-    from parity import teacher_forced
+    from parity import describe, teacher_forced
     cfg, m, ids, seq, hist, trace = full
     d = ref_cpu.Dims()
     assert (d.vocab, d.hidden, d.layers, d.mask_id) == (cfg.vocab_size, cfg.hidden_size, cfg.num_hidden_layers, cfg.mask_token_id)
@@ -136,10 +136,7 @@ def test_c2_teacher_forced_sample_vs_cpu_oracle(full):
         sub_trace.append(dict(count=torch.tensor([len(keep)]), dst=new_dst, conf=c2, x0=z2))
     stats, tr = teacher_forced(sd, d, ids[rows], sub_hist, sub_trace, states=states, step_indices=steps,
                                max_new_tokens=G, steps=STEPS, alg="entropy", block_length=BL)
-    print(f"full-size teacher-forced sample (rows {rows}, steps {steps}): {stats['exact_steps']}/{len(steps)} steps identical "
-          f"to the bf16 oracle; {stats['candidates']} candidate rows, {stats['band_tok']} tokens in the declared tie band, "
-          f"max |conf err| {stats['max_conf_err']:.4g} = {stats['max_conf_err_over_tol']:.2f} x tolerance, "
-          f"{len(stats['violations'])} violations")
+    print(f"full-size teacher-forced sample (rows {rows}, steps {steps}): {describe(stats)}")
     assert stats["candidates"] > 100
     assert not stats["violations"], stats["violations"][:5]
 
@@ -155,7 +152,7 @@ def test_full_architecture_stochastic_configs_teacher_forced(full, name, cfg, bl
     C5: topk_margin + alg_temp 0.1, the lm-eval scripts' T = 0.1 + top-p, the serving defaults) on the full
     architecture (28 layers, V = 151 936) at a shape the CPU oracle finishes in seconds: the oracle's noise is
     replayed into the HIP kernels and every step is compared teacher-forced."""
-    from parity import teacher_forced
+    from parity import describe, teacher_forced
     from test_hip_e2e import Replay
     cfg_m, m, _, _, _, _ = full
     d = ref_cpu.Dims()
@@ -172,8 +169,6 @@ def test_full_architecture_stochastic_configs_teacher_forced(full, name, cfg, bl
     hist = [h.cpu() for h in out.history]
     stats, tr = teacher_forced(sd, d, ids, hist, trace, noise_log=noise.log, **kw)
     rate = (out.sequences.cpu() == ref.sequences).float().mean().item()
-    print(f"full architecture, {name}: free-running token match {rate:.3f}; teacher-forced {stats['exact_steps']}/8 steps identical, "
-          f"{stats['band_tok']} tok-band, max conf err {stats['max_conf_err']:.4g} = {stats['max_conf_err_over_tol']:.2f} x tol, "
-          f"{len(stats['violations'])} violations")
+    print(f"full architecture, {name}: free-running token match {rate:.3f}; teacher-forced {describe(stats)}")
     assert (out.sequences != cfg_m.mask_token_id).all()
     assert not stats["violations"], stats["violations"][:5]

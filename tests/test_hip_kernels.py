@@ -40,13 +40,19 @@ def _release_kept_tensors():
     _KEEP.clear()
 
 
-def gemm(X, W, epi, R=None, rows=None, M=None, out_cols=None):
+def gemm(X, W, epi, R=None, rows=None, M=None, out_cols=None, engine=0, flags=0):
+    """engine / flags != 0: the tile engine and store width are the CALL's arguments (coda_gemm_bf16_ex); the library
+    keeps no selection state."""
     M = X.shape[0] if M is None else M
     N, K = W.shape
     cols = out_cols or (N // 2 if epi == _lib.EPI_SWIGLU else N)
     C = torch.full((M, cols), float("nan"), device=DEV, dtype=torch.float32 if epi == _lib.EPI_F32 else BF)
-    _lib.call("coda_gemm_bf16", _p(X), X.stride(0), _p(rows), _p(W), W.stride(0), _p(C), C.stride(0), _p(R),
-              0 if R is None else R.stride(0), M, N, K, epi, _s())
+    if engine or flags:
+        _lib.call("coda_gemm_bf16_ex", _p(X), X.stride(0), _p(rows), _p(W), W.stride(0), _p(C), C.stride(0), _p(R),
+                  0 if R is None else R.stride(0), M, N, K, epi, engine, flags, _s())
+    else:
+        _lib.call("coda_gemm_bf16", _p(X), X.stride(0), _p(rows), _p(W), W.stride(0), _p(C), C.stride(0), _p(R),
+                  0 if R is None else R.stride(0), M, N, K, epi, _s())
     torch.cuda.synchronize()
     return C
 
@@ -72,45 +78,41 @@ def test_gemm_exact_integer(M, N, K):
                                        (1024, 768, 2048, "res"), (515, 512, 320, "res"), (8192, 5120, 128, "plain"),
                                        (8192 + 40, 4096 + 128, 64, "res")])
 def test_gemm_engines_exact_integer(variant, M, N, K, epi, wide):
-    """Every tile engine (forced through coda_gemm_select) on exact integer data, with the interior tiles' stores as
-    16-byte pieces (v_permlane16_swap exchange, the default) and as 8-byte pieces."""
-    lib = _lib.load()
-    assert lib.coda_gemm_select(variant) == 0
-    lib.coda_gemm_wide_stores(wide)
-    try:
-        X, W = int_mat((M, K), -3, 3, 21), int_mat((N, K), -2, 2, 22)
-        ref = X.float() @ W.float().t()
-        assert ref.abs().max() < 2 ** 24
-        if epi == "f32":
-            assert torch.equal(gemm(X.to(DEV), W.to(DEV), _lib.EPI_F32).cpu(), ref)
-        elif epi == "plain":
-            assert torch.equal(gemm(X.to(DEV), W.to(DEV), _lib.EPI_PLAIN).cpu(), ref.to(BF))
-        else:
-            R = int_mat((M, N), -50, 50, 23)
-            want = (ref.to(BF).float() + R.float()).to(BF)
-            assert torch.equal(gemm(X.to(DEV), W.to(DEV), _lib.EPI_RESIDUAL, R=R.to(DEV)).cpu(), want)
-    finally:
-        lib.coda_gemm_select(0)
-        lib.coda_gemm_wide_stores(1)
+    """Every tile engine (forced per call through coda_gemm_bf16_ex) on exact integer data, with the interior tiles'
+    stores as 16-byte pieces (v_permlane16_swap exchange, the default) and as 8-byte pieces."""
+    fl = 0 if wide else _lib.GEMM_NARROW_STORES
+    X, W = int_mat((M, K), -3, 3, 21), int_mat((N, K), -2, 2, 22)
+    ref = X.float() @ W.float().t()
+    assert ref.abs().max() < 2 ** 24
+    if epi == "f32":
+        assert torch.equal(gemm(X.to(DEV), W.to(DEV), _lib.EPI_F32, engine=variant, flags=fl).cpu(), ref)
+    elif epi == "plain":
+        assert torch.equal(gemm(X.to(DEV), W.to(DEV), _lib.EPI_PLAIN, engine=variant, flags=fl).cpu(), ref.to(BF))
+    else:
+        R = int_mat((M, N), -50, 50, 23)
+        want = (ref.to(BF).float() + R.float()).to(BF)
+        assert torch.equal(gemm(X.to(DEV), W.to(DEV), _lib.EPI_RESIDUAL, R=R.to(DEV), engine=variant, flags=fl).cpu(), want)
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7])
 def test_gemm_engines_swiglu(variant):
     from coda_amd.engine import interleave_gate_up
-    lib = _lib.load()
-    lib.coda_gemm_select(variant)
-    try:
-        M, I, K = 520, 384, 256
-        Wg, Wu = int_mat((I, K), -1, 1, 31), int_mat((I, K), -2, 2, 32)
-        X = int_mat((M, K), -1, 1, 33)
-        gate, up = (X.float() @ Wg.float().t()).to(BF), (X.float() @ Wu.float().t()).to(BF)
-        ref = torch.nn.functional.silu(gate) * up
-        out = gemm(X.to(DEV), interleave_gate_up(Wg, Wu).to(DEV), _lib.EPI_SWIGLU).cpu()
-        # integer operands: gate/up are exact, only silu's exp differs between host and device libm
-        assert (out.float() - ref.float()).abs().max() <= 2.0 ** -7 * ref.float().abs().max()
-        assert (out == ref).float().mean() > 0.99
-    finally:
-        lib.coda_gemm_select(0)
+    M, I, K = 520, 384, 256
+    Wg, Wu = int_mat((I, K), -1, 1, 31), int_mat((I, K), -2, 2, 32)
+    X = int_mat((M, K), -1, 1, 33)
+    gate, up = (X.float() @ Wg.float().t()).to(BF), (X.float() @ Wu.float().t()).to(BF)
+    ref = torch.nn.functional.silu(gate) * up
+    out = gemm(X.to(DEV), interleave_gate_up(Wg, Wu).to(DEV), _lib.EPI_SWIGLU, engine=variant).cpu()
+    # integer operands: gate/up are exact, only silu's exp differs between host and device libm
+    assert (out.float() - ref.float()).abs().max() <= 2.0 ** -7 * ref.float().abs().max()
+    assert (out == ref).float().mean() > 0.99
+
+
+def test_gemm_ex_rejects_unknown_engine():
+    X = torch.zeros(64, 64, device=DEV, dtype=BF)
+    C = torch.zeros(64, 64, device=DEV, dtype=BF)
+    rc = _lib.load().coda_gemm_bf16_ex(_p(X), 64, None, _p(X), 64, _p(C), 64, None, 0, 64, 64, 64, 0, 9, 0, _s())
+    assert rc == -4
 
 
 def test_gemm_identity_asymmetric():
@@ -295,21 +297,22 @@ def test_flash_attention(B, L, n_q, n_kv):
 
 
 @pytest.mark.parametrize("B,L,n_q,n_kv", [(2, 100, 4, 2), (3, 517, 4, 1), (4, 640, 16, 8), (1, 2048, 16, 8)])
-def test_flash_attention_head_pairs_bit_identical(B, L, n_q, n_kv, monkeypatch):
+def test_flash_attention_head_pairs_bit_identical(B, L, n_q, n_kv):
     """From L = 512 on a workgroup runs the two query heads of a GQA pair on one K/V stream (8 waves); the per-wave
-    arithmetic is the same, so both variants must agree bit for bit (CODA_ATTN_PAIR forces either)."""
+    arithmetic is the same, so both variants must agree bit for bit (pair_mode of coda_flash_attn_noncausal_ex forces
+    either), and so must any number of workgroups per (batch, head)."""
     g = torch.Generator().manual_seed(13)
     d, T = 128, B * L
     qkv = torch.randn(T, (n_q + 2 * n_kv) * d, generator=g).to(BF).to(DEV)
     outs = []
-    for pair in ("0", "1"):
-        monkeypatch.setenv("CODA_ATTN_PAIR", pair)
+    for pair, qsplit in ((0, 0), (1, 0), (-1, 0), (0, 1), (1, 2)):
         out = torch.full((T, n_q * d), float("nan"), device=DEV, dtype=BF)
-        _lib.call("coda_flash_attn_noncausal", _p(qkv), qkv.stride(0), _p(out), n_q * d, B, L, n_q, n_kv, 1.0 / math.sqrt(d), _s())
+        _lib.call("coda_flash_attn_noncausal_ex", _p(qkv), qkv.stride(0), _p(out), n_q * d, B, L, n_q, n_kv, 1.0 / math.sqrt(d),
+                  pair, qsplit, _s())
         torch.cuda.synchronize()
         outs.append(out)
     assert not torch.isnan(outs[1].float()).any()
-    assert torch.equal(outs[0], outs[1])
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
 def test_flash_attention_exact_uniform():
@@ -401,10 +404,82 @@ def test_select_unmask_matches_oracle(alg_temp):
         src, dst, cnt = _candidates(x, lo, hi, mask_id)
         kd = torch.zeros(1, device=DEV, dtype=torch.int32)
         _lib.call("coda_select_unmask", _p(xd), _p(conf.to(DEV).contiguous()), _p(x0.to(DEV)), _p(cnt), B, L, lo, hi, mask_id,
-                  ratio, int(last), alg_temp, _p(noise.to(DEV)), _p(kd), _s())
+                  ratio, int(last), alg_temp, _p(noise.to(DEV)), 0, _p(kd), _s())
         torch.cuda.synchronize()
         assert kd.item() == k, (trial, kd.item(), k)
         assert torch.equal(xd.cpu(), expect), trial
+
+
+def hash_uniform_host(seed: int, rowkey: torch.Tensor, v: int) -> torch.Tensor:
+    """Host restatement of coda_hash_uniform (csrc/coda_common.h): uniform in (0, 1) from (seed, row key, index)."""
+    M = 0xFFFFFFFF
+    lo, hi = seed & M, (seed >> 32) & M
+    h = ((v * 0x9E3779B1) & M) ^ ((rowkey.to(torch.int64) * 0x85EBCA77) & M) ^ lo
+    h = h ^ (h >> 16); h = (h * 0x85EBCA6B) & M; h = h ^ (h >> 13); h = (h * 0xC2B2AE35) & M; h = h ^ (h >> 16)
+    h = (h + hi) & M
+    h = h ^ (h >> 15); h = (h * 0x2C1B3C6D) & M; h = h ^ (h >> 12); h = (h * 0x297A2D39) & M; h = h ^ (h >> 15)
+    return ((h >> 8).to(torch.float32) + 0.5) * (1.0 / 16777216.0)
+
+
+def test_select_unmask_in_kernel_noise_matches_host_hash():
+    """alg_temp > 0 with noise == NULL: the kernel's own Exp(1) variates (-log of the counter hash) must select what
+    the reference rule selects with the host restatement of the same hash; other seeds select differently."""
+    g = torch.Generator().manual_seed(44)
+    B, L, P, mask_id, alg_temp, seed = 6, 200, 20, 7, 0.25, 0x1234_5678_9ABC_DEF1
+    x = torch.randint(10, 50, (B, L), generator=g)
+    x[:, P:][torch.rand(B, L - P, generator=g) < 0.7] = mask_id
+    conf = -torch.rand(B, L, generator=g) * 2
+    x0 = torch.randint(100, 200, (B, L), generator=g)
+    mask_index = x == mask_id
+    pos = torch.arange(B * L).reshape(B, L)
+    q = -torch.log(hash_uniform_host(seed, pos, 0xFFFFFFFF))
+    assert 0.5 < q.mean() < 1.5 and q.min() > 0                              # Exp(1)-like
+    ratio = 0.2
+    k = int((mask_index.sum() / B) * torch.tensor(ratio))
+    full = torch.full((B, L), -torch.inf)
+    full[mask_index] = conf[mask_index]
+    key = torch.softmax(full / alg_temp, -1) / q
+    expect = x.clone()
+    margins = []
+    for b in range(B):
+        order = sorted(mask_index[b].nonzero().squeeze(1).tolist(), key=lambda p: (-key[b, p].item(), p))
+        expect[b, order[:k]] = x0[b, order[:k]]
+        margins.append(key[b, order[k - 1]].item() / key[b, order[k]].item() - 1)
+    outs = []
+    for sd in (seed, seed + 1):
+        xd = x.to(DEV)
+        src, dst, cnt = _candidates(x, P, L, mask_id)
+        _lib.call("coda_select_unmask", _p(xd), _p(conf.to(DEV).contiguous()), _p(x0.to(DEV)), _p(cnt), B, L, P, L, mask_id,
+                  ratio, 0, alg_temp, None, sd, None, _s())
+        torch.cuda.synchronize()
+        outs.append(xd.cpu())
+    # device __logf / __expf vs host libm: a decision can only differ where the k-th / (k+1)-th keys are within ~1e-5
+    if min(margins) > 1e-4:
+        assert torch.equal(outs[0], expect)
+    else:
+        assert (outs[0] != expect).sum() <= 2
+    assert ((outs[0] != x).sum(1) == k).all()
+    assert not torch.equal(outs[0], outs[1])
+
+
+def test_origin_transfer_in_kernel_uniforms():
+    g = torch.Generator().manual_seed(45)
+    B, L, mask_id, seed = 3, 500, 7, 987654321987
+    x = torch.randint(10, 50, (B, L), generator=g)
+    x[torch.rand(B, L, generator=g) < 0.5] = mask_id
+    x0 = torch.randint(100, 200, (B, L), generator=g)
+    src, dst, cnt = _candidates(x, 0, L, mask_id)
+    n = cnt.item()
+    u = hash_uniform_host(seed, dst[:n].cpu().long(), 0xFFFFFFFE)
+    for p_t in (0.3, 1.0, 0.0):
+        xd = x.to(DEV)
+        _lib.call("coda_origin_transfer", _p(xd), _p(x0.to(DEV)), _p(dst), _p(cnt), B * L, None, seed, p_t, _s())
+        torch.cuda.synchronize()
+        expect = x.clone().reshape(-1)
+        take = dst[:n].cpu().long()[u < p_t]
+        expect[take] = x0.reshape(-1)[take]
+        assert torch.equal(xd.cpu().reshape(-1), expect), p_t
+    assert abs((u < 0.3).float().mean().item() - 0.3) < 0.05
 
 
 def test_select_threshold_matches_reference_rule():
@@ -544,7 +619,11 @@ def test_confidence_from_logits_all_flavours(V, golden):
         def token_exp(self, step, probs):
             return q
     cases = [dict(), dict(top_p=0.9), dict(top_k=50), dict(top_p=0.7, top_k=30), dict(top_p=0.95, top_k=5),
-             dict(temperature=0.7, top_p=0.9), dict(temperature=1.3, top_k=20), dict(temperature=0.5)]
+             dict(temperature=0.7, top_p=0.9), dict(temperature=1.3, top_k=20), dict(temperature=0.5),
+             # the lm-eval scripts' setting (eval_mbpp_humaneval.sh: T = 0.1, top_p = 0.9): exact logits in, so this is
+             # the tight check of generation_utils.py:61-100 at low temperature (the e2e bands are wide there)
+             dict(temperature=0.1), dict(temperature=0.1, top_p=0.9), dict(temperature=0.1, top_k=40),
+             dict(temperature=0.1, top_p=0.9, top_k=10)]
     for kw in cases:
         for alg_id, okw in ((0, {}), (1, dict(margin=True)), (2, dict(neg_entropy=True))):
             t = kw.get("temperature", 0.0)
@@ -589,3 +668,44 @@ def test_confidence_from_logits_bf16_ties():
         # the cumulative mass is summed in a different order than torch.cumsum: a boundary tie may flip
         close = (conf - ent_ref).abs() < 2e-4
         assert close.float().mean() >= 0.8, (top_p, top_k, (conf - ent_ref).abs())
+
+
+@pytest.mark.parametrize("scale,top_p", [(0.05, 0.9), (0.3, 0.95), (2.0, 0.8)])
+def test_confidence_top_p_tie_cut_negative_threshold(scale, top_p):
+    """Flat bf16 rows (early denoise steps) put the nucleus boundary in the NEGATIVE tail, among many equal logits.
+    The reference keeps boundary ties one by one while the running mass <= top_p (top_p_logits, generation_utils.py:39-50;
+    stable order = index order here).  maskgit_plus at T = 0 returns 1 / Z_kept, so the kept mass - and from it the number
+    of boundary ties kept - can be read back from the confidence and compared with a float64 stable-sort oracle."""
+    g = torch.Generator().manual_seed(23)
+    N, V = 12, 8192
+    logits = (torch.randn(N, V, generator=g) * scale).to(BF)
+    lf = logits.double()
+    srt, idx = torch.sort(lf, dim=-1, descending=True, stable=True)
+    e = torch.exp(srt - srt[:, :1])
+    ps = e / e.sum(-1, keepdim=True)
+    excl = torch.cumsum(ps, -1) - ps
+    kept_sorted = excl <= top_p
+    kept_sorted[:, 0] = True
+    n_keep = kept_sorted.sum(-1)
+    thr = srt.gather(1, (n_keep - 1)[:, None]).squeeze(1)                  # value of the last kept entry
+    if scale < 1:
+        assert (thr < 0).all(), "the case must put the boundary on a negative logit"
+    n_above = (lf > thr[:, None]).sum(-1)
+    ties_total = (lf == thr[:, None]).sum(-1)
+    ties_kept_ref = n_keep - n_above
+    assert (ties_total > ties_kept_ref).any(), "no row cuts inside a tie group: the case does not test the cut"
+    z_above = (torch.exp(lf - srt[:, :1]) * (lf > thr[:, None])).sum(-1)
+    conf, x0 = _conf_logits(logits, 0, 0.0, top_p, 0)
+    z_hip = 1.0 / conf.double()
+    ties_kept_hip = (z_hip - z_above) / torch.exp(thr - srt[:, 0])
+    print(f"top-p tie cut (scale {scale}): ties at the boundary {ties_total.tolist()}, kept ref {ties_kept_ref.tolist()}, "
+          f"kept hip {[round(float(t), 2) for t in ties_kept_hip]}")
+    assert torch.equal(x0, lf.argmax(-1))
+    # fp32 sums over ~8k kept entries: the tie count read back from 1/conf is good to a fraction of a tie
+    assert ((ties_kept_hip - ties_kept_ref.double()).abs() <= 1.25).all()
+    # the kept index set: entropy over it must match too (index order of the kept ties does not change the value)
+    keep = torch.zeros(N, V, dtype=torch.bool).scatter_(1, idx, kept_sorted)
+    pr = torch.softmax(lf.masked_fill(~keep, -1e30), -1)
+    ent_ref = (pr * torch.log(pr + 1e-10)).sum(-1)
+    conf_e, _ = _conf_logits(logits, 2, 0.0, top_p, 0)
+    assert (conf_e.double() - ent_ref).abs().max() < 2e-3

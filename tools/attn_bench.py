@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Times the flash attention kernel on the decoder's shapes (random data).  QSPLITS=1,2,4 additionally forces the
-number of workgroups per (batch, head) through CODA_ATTN_QSPLIT, interleaved in one process (A/B)."""
+number of workgroups per (batch, head) (KNOB=qsplit, default) or the head-pair mode (KNOB=pair: 1 = off, 2 = on) through
+coda_flash_attn_noncausal_ex's per-call arguments, interleaved in one process (A/B)."""
 import math
 import os
 import sys
@@ -12,7 +13,7 @@ from coda_amd import _lib  # noqa: E402
 
 _lib.load()
 splits = [0] + [int(v) for v in os.environ.get("QSPLITS", "").split(",") if v]
-KNOB = os.environ.get("KNOB", "CODA_ATTN_QSPLIT")
+KNOB = os.environ.get("KNOB", "qsplit")
 for B, L in ((32, 384), (64, 768), (8, 2048)):
     n_q, n_kv, d = 16, 8, 128
     T = B * L
@@ -20,9 +21,10 @@ for B, L in ((32, 384), (64, 768), (8, 2048)):
     qkv = torch.randn(T, (n_q + 2 * n_kv) * d, device="cuda").to(torch.bfloat16)
     out = torch.empty(T, n_q * d, device="cuda", dtype=torch.bfloat16)
 
-    def run():
-        _lib.call("coda_flash_attn_noncausal", qkv.data_ptr(), qkv.stride(0), out.data_ptr(), n_q * d, B, L, n_q, n_kv,
-                  1.0 / math.sqrt(d), torch.cuda.current_stream().cuda_stream)
+    def run(s=0):
+        pair, qsplit = (s - 1 if s else -1, 0) if KNOB == "pair" else (-1, s)
+        _lib.call("coda_flash_attn_noncausal_ex", qkv.data_ptr(), qkv.stride(0), out.data_ptr(), n_q * d, B, L, n_q, n_kv,
+                  1.0 / math.sqrt(d), pair, qsplit, torch.cuda.current_stream().cuda_stream)
     run()
     torch.cuda.synchronize()
     q = qkv[:L, :d].float()
@@ -33,19 +35,14 @@ for B, L in ((32, 384), (64, 768), (8, 2048)):
     times = {s: [] for s in splits}
     for _ in range(5):
         for s in splits:
-            if s:
-                os.environ[KNOB] = str(s)
-            else:
-                os.environ.pop(KNOB, None)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            run()
+            run(s)
             e0.record()
             for _ in range(20):
-                run()
+                run(s)
             e1.record()
             torch.cuda.synchronize()
             times[s].append(e0.elapsed_time(e1) / 20)
-    os.environ.pop(KNOB, None)
     fl = 4.0 * L * L * d * n_q * B
     for s in splits:
         med = sorted(times[s])[2]

@@ -27,15 +27,15 @@ for shape in shapes:
     s = torch.cuda.current_stream().cuda_stream
     for tag in tags:
         lib = ctypes.CDLL(os.path.join(ROOT, "tools", "probe", f"libcoda_hip_probe_{tag}.so"))
-        lib.coda_gemm_bf16.argtypes = [P, LL, P, P, LL, P, LL, P, LL, I, I, I, I, P]
-        lib.coda_gemm_bf16.restype = I
+        lib.coda_gemm_bf16_ex.argtypes = [P, LL, P, P, LL, P, LL, P, LL, I, I, I, I, I, I, P]
+        lib.coda_gemm_bf16_ex.restype = I
         lib.coda_gemm_probe.argtypes = [P]
-        lib.coda_gemm_select(int(os.environ.get("GEMM_VARIANT", "0")))
+        variant = int(os.environ.get("GEMM_VARIANT", "0"))
         lib.coda_gemm_probe(dbg.data_ptr())
 
         def go():
-            rc = lib.coda_gemm_bf16(X.data_ptr(), K, None, W.data_ptr(), K, C.data_ptr(), cols, C.data_ptr() if epi == 1 else None,
-                                    cols if epi == 1 else 0, M, N, K, epi, s)
+            rc = lib.coda_gemm_bf16_ex(X.data_ptr(), K, None, W.data_ptr(), K, C.data_ptr(), cols, C.data_ptr() if epi == 1 else None,
+                                       cols if epi == 1 else 0, M, N, K, epi, variant, 0, s)
             assert rc == 0, rc
         go()
         torch.cuda.synchronize()

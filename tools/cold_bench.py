@@ -23,7 +23,6 @@ for name, N, K, epi in (("qkv", 4096, 2048, 0), ("o_proj", 2048, 2048, 1), ("gat
     cols = N // 2 if epi == 2 else N
     C = torch.randn(M, cols, device=DEV).to(BF)
     for v in variants:
-        lib.coda_gemm_select(v)
         out = []
         for label, rw, rx in (("hot", 0, 0), ("W cold", 1, 0), ("X cold", 0, 1), ("both cold", 1, 1)):
             ts = []
@@ -34,11 +33,11 @@ for name, N, K, epi in (("qkv", 4096, 2048, 0), ("o_proj", 2048, 2048, 1), ("gat
                     if it == 2:
                         e0.record()
                     X, W = Xs[it % nX if rx else 0], Ws[it % nW if rw else 0]
-                    _lib.call("coda_gemm_bf16", X.data_ptr(), K, None, W.data_ptr(), K, C.data_ptr(), cols,
-                              C.data_ptr() if epi == 1 else None, cols if epi == 1 else 0, M, N, K, epi, torch.cuda.current_stream().cuda_stream)
+                    _lib.call("coda_gemm_bf16_ex", X.data_ptr(), K, None, W.data_ptr(), K, C.data_ptr(), cols,
+                              C.data_ptr() if epi == 1 else None, cols if epi == 1 else 0, M, N, K, epi, v, 0,
+                              torch.cuda.current_stream().cuda_stream)
                 e1.record()
                 torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) / n * 1e3)
             out.append(f"{label}: {sorted(ts)[1]:.1f}")
         print(f"{name:8s} v{v} ({nW} W, {nX} X buffers) " + " | ".join(out) + " us", flush=True)
-lib.coda_gemm_select(0)

@@ -14,10 +14,11 @@ BF = torch.bfloat16
 lib = _lib.load()
 
 
-def run(X, W, C, R, epi):
-    _lib.call("coda_gemm_bf16", X.data_ptr(), X.stride(0), None, W.data_ptr(), W.stride(0), C.data_ptr(), C.stride(0),
+def run(X, W, C, R, epi, v=0):
+    """v = engine number (coda_gemm_bf16_ex), + 100 = same engine with 8-byte epilogue stores."""
+    _lib.call("coda_gemm_bf16_ex", X.data_ptr(), X.stride(0), None, W.data_ptr(), W.stride(0), C.data_ptr(), C.stride(0),
               None if R is None else R.data_ptr(), 0 if R is None else R.stride(0), X.shape[0], W.shape[0], X.shape[1], epi,
-              torch.cuda.current_stream().cuda_stream)
+              v % 100, _lib.GEMM_NARROW_STORES if v >= 100 else 0, torch.cuda.current_stream().cuda_stream)
 
 
 def main():
@@ -35,10 +36,8 @@ def main():
         R = torch.randn(M, N, device=DEV, dtype=torch.float32).to(BF) if epi == 1 else None
         outs = {}
         for v in variants:
-            lib.coda_gemm_select(v % 100)
-            lib.coda_gemm_wide_stores(0 if v >= 100 else 1)        # variant + 100 = same engine, 8-byte stores
             C = torch.zeros(M, cols, device=DEV, dtype=BF)
-            run(X, W, C, R, epi)
+            run(X, W, C, R, epi, v)
             torch.cuda.synchronize()
             outs[v] = C.float()
         ref = X.float() @ W.float().t()
@@ -55,14 +54,12 @@ def main():
         times = {v: [] for v in variants}
         for rnd in range(5):
             for v in variants:
-                lib.coda_gemm_select(v % 100)
-                lib.coda_gemm_wide_stores(0 if v >= 100 else 1)
                 C = torch.empty(M, cols, device=DEV, dtype=BF)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                run(X, W, C, R, epi)
+                run(X, W, C, R, epi, v)
                 e0.record()
                 for _ in range(20):
-                    run(X, W, C, R, epi)
+                    run(X, W, C, R, epi, v)
                 e1.record()
                 torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) / 20)
@@ -71,8 +68,6 @@ def main():
             med = sorted(times[v])[len(times[v]) // 2]
             msg.append(f"v{v} {med*1e3:7.1f} us {fl/med/1e9:7.1f} TF (min {min(times[v])*1e3:.1f} us)")
         print(" | ".join(msg), flush=True)
-    lib.coda_gemm_select(0)
-    lib.coda_gemm_wide_stores(1)
 
 
 if __name__ == "__main__":

@@ -16,8 +16,7 @@ W = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
 R = torch.randn(M, N, device="cuda").to(torch.bfloat16) if epi == 1 else None
 C = torch.empty(M, N // 2 if epi == 2 else N, device="cuda", dtype=torch.bfloat16)
 for v in [int(a) for a in sys.argv[1:]] or [1, 2]:
-    lib.coda_gemm_select(v)
     for _ in range(6):
-        _lib.call("coda_gemm_bf16", X.data_ptr(), K, None, W.data_ptr(), K, C.data_ptr(), C.stride(0),
-                  None if R is None else R.data_ptr(), 0 if R is None else N, M, N, K, epi, torch.cuda.current_stream().cuda_stream)
+        _lib.call("coda_gemm_bf16_ex", X.data_ptr(), K, None, W.data_ptr(), K, C.data_ptr(), C.stride(0),
+                  None if R is None else R.data_ptr(), 0 if R is None else N, M, N, K, epi, v, 0, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()

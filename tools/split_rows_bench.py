@@ -10,10 +10,9 @@ DEV, BF = "cuda", torch.bfloat16
 M, NB = 12288, 6
 
 def run(X, W, C, R, m0, m1, variant):
-    lib.coda_gemm_select(variant)
     Xs, Cs, Rs = X[m0:m1], C[m0:m1], R[m0:m1]
-    _lib.call("coda_gemm_bf16", Xs.data_ptr(), X.stride(0), None, W.data_ptr(), W.stride(0), Cs.data_ptr(), C.stride(0),
-              Rs.data_ptr(), R.stride(0), m1 - m0, W.shape[0], X.shape[1], 1, torch.cuda.current_stream().cuda_stream)
+    _lib.call("coda_gemm_bf16_ex", Xs.data_ptr(), X.stride(0), None, W.data_ptr(), W.stride(0), Cs.data_ptr(), C.stride(0),
+              Rs.data_ptr(), R.stride(0), m1 - m0, W.shape[0], X.shape[1], 1, variant, 0, torch.cuda.current_stream().cuda_stream)
 
 torch.manual_seed(0)
 for name, N, K in (("o_proj", 2048, 2048), ("down", 2048, 6144)):
@@ -51,4 +50,3 @@ for name, N, K in (("o_proj", 2048, 2048), ("down", 2048, 6144)):
     for pname in plans:
         t = sorted(times[pname])
         print(f"{name:7s} {pname:34s} median {t[len(t)//2]:7.1f} us  min {t[0]:7.1f} us", flush=True)
-lib.coda_gemm_select(0)
