@@ -39,6 +39,20 @@ def gather_completions(local: torch.Tensor, dist=None, n_total: Optional[int] = 
     return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0).to(home)
 
 
+def gather_metrics(vec: torch.Tensor, dist=None) -> torch.Tensor:
+    """all_gather of one small fp32 metrics vector per rank -> [world, len(vec)] on every rank (rank order): the
+    counterpart of the reference's per-rank counts / metrics gather (evaluator.py:523-526,620-642)."""
+    vec = vec.reshape(-1).to(torch.float32)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return vec[None, :].clone()
+    home = vec.device
+    if vec.is_cuda and dist.get_backend() == "gloo":
+        vec = vec.cpu()
+    out = [torch.empty_like(vec) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, vec.contiguous())
+    return torch.stack(out, dim=0).to(home)
+
+
 def generate_data_parallel(generate: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.Tensor, dist=None):
     """Every rank holds the same [B_total, P] prompts, generates its shard with `generate`
     (e.g. lambda ids: model.diffusion_generate(ids, ...)) and receives all completions in prompt order."""

@@ -216,6 +216,12 @@ def sample_tokens(logits: torch.Tensor, temperature: float = 0.0, top_p=None, to
     if temperature > 0:
         logits = logits / temperature
     if top_p is not None and top_p < 1:
+        if diag is not None and logits.shape[0]:
+            # mass that lies BEFORE every token in the nucleus order (same sort as top_p_filter): lets a parity test tell
+            # whether a token's membership of the nucleus is decided by less than the stated logit tolerance
+            srt, order = torch.sort(logits, descending=True)
+            ps = F.softmax(srt.float(), dim=-1)
+            diag["nucleus_excl"] = torch.zeros_like(ps).scatter_(-1, order, torch.cumsum(ps, dim=-1) - ps)
         logits = top_p_filter(logits, top_p)
     if top_k is not None:
         logits = top_k_filter(logits, top_k)
@@ -291,6 +297,7 @@ class SamplerTrace:
     cand: List[torch.Tensor] = field(default_factory=list)
     gap: List[torch.Tensor] = field(default_factory=list)
     absmax: List[torch.Tensor] = field(default_factory=list)     # largest |logit| of every candidate row
+    nucleus: List[Optional[torch.Tensor]] = field(default_factory=list)   # top-p only: [n, V] mass before each token
     pmax: List[torch.Tensor] = field(default_factory=list)       # largest probability of every candidate row
 
 
@@ -367,6 +374,7 @@ def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: to
                     gap[pick] = dg["gap"]
                 tr.x0.append(x0.clone()); tr.gap.append(gap); tr.cand.append(mask_index.clone())
                 tr.key.append(None); tr.k.append(None); tr.absmax.append(None); tr.conf.append(None); tr.pmax.append(None)
+                tr.nucleus.append(None)
         elif args.alg == "confidence_threshold":
             # serving/dream/model/generation_utils.py:442-465 (the serving sampler bound onto the CoDA model by
             # serving/fast-api/app/core/service.py:99-120)
@@ -398,7 +406,7 @@ def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: to
                 tr.conf.append(conf.clone()); tr.x0.append(x0.clone()); tr.k.append(current)
                 tr.chosen.append(transfer.nonzero()); tr.key.append(full.float()); tr.cand.append(mask_index.clone())
                 tr.gap.append(dg.get("gap", torch.zeros(0))); tr.absmax.append(dg.get("absmax", torch.zeros(0)))
-                tr.pmax.append(dg.get("pmax", torch.zeros(0)))
+                tr.pmax.append(dg.get("pmax", torch.zeros(0))); tr.nucleus.append(dg.get("nucleus_excl"))
         else:
             if args.alg not in ("maskgit_plus", "topk_margin", "entropy"):
                 raise RuntimeError(f"Unknown alg: {args.alg}")
@@ -429,7 +437,7 @@ def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: to
                 tr.conf.append(conf.clone()); tr.x0.append(x0.clone()); tr.k.append(k); tr.chosen.append(chosen)
                 tr.key.append(sel_key.float().masked_fill(~mask_index, -torch.inf)); tr.cand.append(mask_index.clone())
                 tr.gap.append(dg.get("gap", torch.zeros(0))); tr.absmax.append(dg.get("absmax", torch.zeros(0)))
-                tr.pmax.append(dg.get("pmax", torch.zeros(0)))
+                tr.pmax.append(dg.get("pmax", torch.zeros(0))); tr.nucleus.append(dg.get("nucleus_excl"))
         if tokens_hook is not None:
             x = tokens_hook(i, x, logits)
         if args.output_history or trace:

@@ -7,7 +7,9 @@ from the HIP path's x at every step), so one near-tie cannot cascade.  Per step 
                runner-up distance is inside the declared near-tie band: greedy - top-2 logits within
                BAND_TOK (two bf16 ulps, relative); sampling - the relative gap of the two best race keys
                p/q at most 1 - e^-u, u = two bf16 ulps of the row's largest PRE-division logit, amplified
-               by 1/T, plus two ulps of the bf16 quotient (logit_band(), token_band()).
+               by 1/T, plus two ulps of the bf16 quotient (logit_band(), token_band()); with top-p also where
+               either path's token sits on the nucleus boundary (the mass in front of it crosses top_p under
+               the same logit band).
   confidence   for candidates whose token agrees, |conf_hip - conf_oracle| <= conf_tolerance(...):
                what a two-ulp change of the row's largest bf16 logit does to the confidence, plus
                the oracle's own bf16 rounding of the confidence.  (Logits are bf16 in the reference;
@@ -68,7 +70,8 @@ def conf_tolerance(conf_o: torch.Tensor, absmax: torch.Tensor, pmax: torch.Tenso
 def describe(st) -> str:
     """One line for test output: the error is printed next to the tolerance it was held against."""
     return (f"{st['exact_steps']}/{st['steps']} steps identical to the bf16 oracle; {st['candidates']} candidate rows, "
-            f"{st['band_tok']} tokens inside the declared band (largest band used {st['max_band']:.3g}); "
+            f"{st['band_tok']} tokens inside the declared band (largest band used {st['max_band']:.3g}"
+            + (f", {st['band_nucleus']} of them by nucleus membership" if st.get("band_nucleus") else "") + "); "
             f"max |conf err| {st['max_conf_err']:.4g}, worst err/tol {st['max_conf_err_over_tol']:.2f} (tol there {st['tol_at_max']:.3g}); "
             f"{len(st['violations'])} violations")
 
@@ -127,9 +130,23 @@ def teacher_forced(sd, d, ids, hip_hist, hip_trace, noise_log=None, states=None,
         gap = tr.gap[i]
         tok_bad = x0_h != x0_o
         band = token_band(tr.absmax[i], temperature)
-        st["band_tok"] += int((tok_bad & (gap <= band)).sum())
-        if (tok_bad & (gap > band)).any():
-            st["violations"].append((i, f"token differs outside band, gaps {gap[tok_bad & (gap > band)].tolist()}"))
+        excused = gap <= band
+        top_p = kw.get("top_p")
+        if top_p is not None and top_p < 1 and tr.nucleus[i] is not None and n:
+            # top-p: the race runs over the nucleus only, and membership is a threshold on cumulative mass.  A token is
+            # "on the boundary" when the mass in front of it (oracle's order), scaled by what the logit band does to
+            # probabilities (e^+-u), crosses top_p; the oracle also compares a bf16-rounded cumsum with a bf16-rounded
+            # top_p (one bf16 step near 0.9 = 2^-8).  The oracle's token may then be outside the HIP path's nucleus, or
+            # the HIP path's token outside the oracle's: either explains a different winner whatever the race gap.
+            u = logit_band(tr.absmax[i], temperature)
+            ar = torch.arange(n)
+            c_o, c_h = tr.nucleus[i][ar, x0_o], tr.nucleus[i][ar, x0_h.clamp(0, tr.nucleus[i].shape[1] - 1)]
+            boundary = (c_o * torch.exp(u) >= top_p - 2.0 ** -8) | ((c_h > top_p - 2.0 ** -8) & (c_h * torch.exp(-u) <= top_p + 2.0 ** -8))
+            st["band_nucleus"] = st.get("band_nucleus", 0) + int((tok_bad & ~excused & boundary).sum())
+            excused = excused | boundary
+        st["band_tok"] += int((tok_bad & excused).sum())
+        if (tok_bad & ~excused).any():
+            st["violations"].append((i, f"token differs outside band, gaps {gap[tok_bad & ~excused].tolist()}"))
         # ---- confidences (only where the token agrees: with sampling the confidence is p[x0])
         ok = ~tok_bad
         conf_o = tr.conf[i].float()

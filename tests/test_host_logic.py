@@ -221,3 +221,28 @@ print("rank ok")
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("rank ok") == 2
+
+
+def test_bench_spawns_its_own_ranks_and_gathers_metrics():
+    """`python bench.py --gpus 2` without a launcher: the parent starts two ranks itself (gloo on the CPU around a stub
+    generate here; RCCL, one rank per GPU, on a node) and rank 0 prints ONE line whose n_gpus is the process group's
+    world size, with the per-rank metrics vector gathered (evaluator.py:523-526)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--stub-cpu",
+                        "--batch", "3", "--prompt", "4", "--new-tokens", "8", "--denoise-steps", "4", "--block-length", "4"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 6 and line["config"]["parallelism"] == "dp2"
+    assert line["config"]["valid"] is False and "STUB" in line["data"]
+    pr = line["per_rank"]
+    assert pr["generated_tokens"] == [3 * 8 * 2.0] * 2 and pr["rows_after_gather"] == [6.0, 6.0]
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 * 2 - 2 * 3 * 8 * 2) < 1e-3      # value = all ranks' tokens / time
+    # a rank that fails takes the run down with a non-zero status instead of hanging the others
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--stub-cpu",
+                        "--new-tokens", "8", "--denoise-steps", "4", "--block-length", "4"],
+                       env=dict(env, CODA_BENCH_TEST_FAIL_RANK="1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "stub rank asked to fail" in r.stderr
