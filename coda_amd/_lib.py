@@ -30,6 +30,7 @@ SIGNATURES = {
     "coda_build_candidates": (_i, [_p, _i, _i, _i, _i, _ll, _p, _p, _p, _p]),
     "coda_lmhead_workspace_bytes": (_ll, [_i, _i]),
     "coda_lmhead_confidence": (_i, [_p, _ll, _p, _p, _p, _i, _p, _ll, _i, _i, _i, _f, _p, _ull, _i, _p, _p, _p, _p]),
+    "coda_lmhead_confidence_noalloc": (_i, [_p, _ll, _p, _p, _p, _i, _p, _ll, _i, _i, _i, _f, _p, _ull, _i, _p, _p, _p]),
     "coda_confidence_from_logits": (_i, [_p, _ll, _i, _i, _i, _p, _p, _i, _f, _f, _i, _p, _ull, _i, _p, _p, _p]),
     "coda_select_unmask": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _ll, _f, _i, _f, _p, _ull, _p, _p]),
     "coda_gather_rows": (_i, [_p, _ll, _p, _p, _i, _p, _ll, _i, _p]),

@@ -11,6 +11,8 @@
 // the 622 MB weight stream over the whole chip and no host sync is needed to size the launch.
 #include "gemm_tile128.h"
 #include "coda_abi_internal.h"
+#include <mutex>
+#include <stdio.h>
 
 using namespace tile128;
 
@@ -273,4 +275,61 @@ extern "C" int coda_lmhead_confidence(const void* hidden, long long ld_hidden, c
                                       float* conf, long long* x0, void* workspace, void* stream) {
     return lmhead_launch(hidden, ld_hidden, src_rows, dst_pos, count, max_rows, W, ldw, V, H, alg, temperature, noise, seed,
                          round_conf_bf16, conf, x0, workspace, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The one entry point that allocates nothing and takes no workspace (callers under HIP graph capture, tight serving
+// loops, harnesses that forbid hipMalloc).  The partial-statistics records go to a file-scope device array instead of
+// a caller workspace: LM_GRID x 128 records of 32 bytes = 4 MiB (+256) per GPU for the life of the process, enough for
+// CODA_LMHEAD_NOALLOC_MAX_ROWS candidate rows (beyond LM_GRID row blocks the vocabulary is no longer split and one
+// record per row is needed - coda_lmhead_workspace_bytes).
+//
+// `lm_scratch` is a HOST-SIDE STAND-IN in host code, not a device address: it is never passed to a kernel.  Its device
+// address is asked for once per device with hipGetSymbolAddress (with that device current - every GPU holds its own
+// copy at its own address) and kept; kernels, as in the entry point above, take the pointer as an argument.
+// Nothing in the records must start at zero: lmhead_combine_kernel reads exactly the records (vocab split < vsplits,
+// candidate < count) that lmhead_partial_kernel of the same call wrote.  All calls on one GPU share the array: calls that
+// overlap on one GPU (two streams, two threads) race on it - serialise them, or use coda_lmhead_confidence with
+// workspaces of your own.
+static __device__ __align__(256) unsigned char lm_scratch[(size_t)LM_GRID * BM * PART_FLOATS * 4 + 256];
+static_assert(CODA_LMHEAD_NOALLOC_MAX_ROWS == LM_GRID * BM, "header constant out of date");
+
+namespace {
+constexpr int LM_MAX_DEV = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[LM_MAX_DEV] = {};     // per device: device address of that GPU's lm_scratch
+}  // namespace
+
+static void* lm_scratch_for_current_device() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LM_MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(lm_scratch));
+        if (e != hipSuccess || !p) {
+            coda_set_last_error("hipGetSymbolAddress(lm_scratch)", e);
+            return nullptr;
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    return g_scratch_ptr[dev];
+}
+
+extern "C" int coda_lmhead_confidence_noalloc(const void* hidden, long long ld_hidden, const int* src_rows,
+                                              const int* dst_pos, const int* count, int max_rows, const void* W,
+                                              long long ldw, int V, int H, int alg, float temperature, const float* noise,
+                                              unsigned long long seed, int round_conf_bf16, float* conf, long long* x0,
+                                              void* stream) {
+    if (max_rows > CODA_LMHEAD_NOALLOC_MAX_ROWS) {
+        char msg[200];
+        snprintf(msg, sizeof(msg), "coda_lmhead_confidence_noalloc: max_rows %d exceeds the static scratch's %d candidate rows "
+                 "(use coda_lmhead_confidence with a caller workspace)", max_rows, CODA_LMHEAD_NOALLOC_MAX_ROWS);
+        coda_set_last_error_msg(msg);
+        return CODA_ERR_SHAPE;
+    }
+    void* part = lm_scratch_for_current_device();
+    if (!part) return CODA_ERR_LAUNCH;
+    return lmhead_launch(hidden, ld_hidden, src_rows, dst_pos, count, max_rows, W, ldw, V, H, alg, temperature, noise, seed,
+                         round_conf_bf16, conf, x0, part, stream);
 }

@@ -144,6 +144,20 @@ int coda_lmhead_confidence(const void* hidden, long long ld_hidden, const int* s
                            float temperature, const float* noise, unsigned long long seed, int round_conf_bf16,
                            float* conf, long long* x0, void* workspace, void* stream);
 
+/* coda_lmhead_confidence for callers that cannot allocate and cannot hand over a workspace (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE (which is PyTorch and
+ * allocates freely): it exists for those callers only.  Same arguments, kernels and results as coda_lmhead_confidence,
+ * minus `workspace`: the partial statistics go to a 4 MiB array that the library holds in each GPU's memory for the
+ * life of the process.  Calls no hipMalloc / hipFree or allocating routine.  Limits: max_rows <=
+ * CODA_LMHEAD_NOALLOC_MAX_ROWS (CODA_ERR_SHAPE beyond, with a message in coda_last_error()); every call on one GPU
+ * shares that GPU's array, so calls that OVERLAP on one GPU (two streams, two threads) race - serialise them.  The first
+ * call on a device looks the array's address up (hipGetSymbolAddress, no allocation): make it outside graph capture. */
+#define CODA_LMHEAD_NOALLOC_MAX_ROWS 131072
+int coda_lmhead_confidence_noalloc(const void* hidden, long long ld_hidden, const int* src_rows, const int* dst_pos,
+                                   const int* count, int max_rows, const void* W, long long ldw, int V, int H, int alg,
+                                   float temperature, const float* noise, unsigned long long seed, int round_conf_bf16,
+                                   float* conf, long long* x0, void* stream);
+
 /* Unfused confidence from materialised logits (hooks, top-p, top-k).  Replaces
  * generation_utils.py:39-100.  logits bf16 or fp32 [N,V] (is_bf16), one row per candidate i < count[0]
  * (count may be NULL: all N rows).  top_p <= 0 or >= 1 disables top-p; top_k <= 0 disables top-k.
