@@ -134,7 +134,7 @@ int coda_build_candidates(const long long* x, int B, int L, int win_lo, int win_
  * noise fp32 [max_rows, V] ~ Exp(1) (the exponential race of Categorical.sample());
  * noise == NULL with temperature > 0: Exp(1) variates come from an in-kernel counter hash of
  * (seed, dst_pos[i], vocab index) - coda_hash_uniform in coda_amd/csrc/coda_common.h, restated on the host by
- * tests/test_hip_kernels.py::hash_uniform_host;
+ * tests/parity.py::hash_uniform_host;
  * confidence per `alg`.  Outputs are written at conf[dst_pos[i]], x0[dst_pos[i]].
  * workspace: coda_lmhead_workspace_bytes(max_rows, V) bytes.  max_rows bounds the grid; rows
  * beyond count[0] do no work.  H % 64 == 0, V % 4 == 0. */

@@ -26,3 +26,25 @@ def separated():
     """Well-separated greedy runs of the reference (tests/golden/make_golden.py separated, section G9)."""
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "separated_vectors.npz"))
+
+
+@pytest.fixture(scope="session")
+def full_model():
+    """The 1.7B architecture (28 layers, V = 151 936) with random-init weights (reference init semantics, lm_head x 8 as
+    in bench.py), built once per GPU test session: (config, model on cuda)."""
+    import torch
+    from coda_amd import CoDAConfig, CoDALanguageModel
+    cfg = CoDAConfig()
+    assert (cfg.num_hidden_layers, cfg.vocab_size, cfg.hidden_size) == (28, 151936, 2048)
+    torch.manual_seed(4321)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device("cuda"):
+            m = CoDALanguageModel(cfg)
+    finally:
+        torch.set_default_dtype(old)
+    m.eval()
+    with torch.no_grad():
+        m.lm_head.weight.mul_(8.0)
+    return cfg, m

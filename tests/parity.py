@@ -67,6 +67,43 @@ def conf_tolerance(conf_o: torch.Tensor, absmax: torch.Tensor, pmax: torch.Tenso
     return (grow + 2.0 ** -7) * base + 1e-4
 
 
+def hash_uniform_host(seed: int, rowkey: torch.Tensor, v) -> torch.Tensor:
+    """Host restatement of coda_hash_uniform (csrc/coda_common.h): uniform in (0, 1) from (seed, row key, index).
+    ``rowkey`` and ``v`` broadcast (int64 tensors or ints)."""
+    M = 0xFFFFFFFF
+    lo, hi = seed & M, (seed >> 32) & M
+    v = torch.as_tensor(v, dtype=torch.int64)
+    h = ((v * 0x9E3779B1) & M) ^ ((torch.as_tensor(rowkey, dtype=torch.int64) * 0x85EBCA77) & M) ^ lo
+    h = h ^ (h >> 16); h = (h * 0x85EBCA6B) & M; h = h ^ (h >> 13); h = (h * 0xC2B2AE35) & M; h = h ^ (h >> 16)
+    h = (h + hi) & M
+    h = h ^ (h >> 15); h = (h * 0x2C1B3C6D) & M; h = h ^ (h >> 12); h = (h * 0x297A2D39) & M; h = h ^ (h >> 15)
+    return ((h >> 8).to(torch.float32) + 0.5) * (1.0 / 16777216.0)
+
+
+def subsample(x_init, hist, trace, rows, steps):
+    """Cuts rows ``rows`` and denoise steps ``steps`` out of a full-size run (history + debug trace) and re-indexes the
+    trace's flat positions to the sub-batch, for teacher_forced(states=..., step_indices=...)."""
+    L = x_init.shape[1]
+    states = [(x_init if i == 0 else hist[i - 1])[rows] for i in steps]
+    sub_hist = [hist[i][rows] for i in steps]
+    sub_trace = []
+    for i in steps:
+        t = trace[i]
+        n = int(t["count"].item())
+        dst = t["dst"][:n].long().cpu()
+        conf, x0 = t["conf"].cpu(), t["x0"].cpu()
+        row_of = dst // L
+        keep = torch.isin(row_of, torch.tensor(rows)).nonzero().squeeze(1)
+        new_row = torch.tensor([rows.index(int(r)) for r in row_of[keep]], dtype=torch.long)
+        new_dst = (new_row * L + dst[keep] % L).to(torch.int32)
+        c2 = torch.zeros(len(rows) * L)
+        z2 = torch.zeros(len(rows) * L, dtype=torch.int64)
+        c2[new_dst.long()] = conf[dst[keep]]
+        z2[new_dst.long()] = x0[dst[keep]]
+        sub_trace.append(dict(count=torch.tensor([len(keep)]), dst=new_dst, conf=c2, x0=z2, orig_dst=dst[keep]))
+    return states, sub_hist, sub_trace
+
+
 def describe(st) -> str:
     """One line for test output: the error is printed next to the tolerance it was held against."""
     return (f"{st['exact_steps']}/{st['steps']} steps identical to the bf16 oracle; {st['candidates']} candidate rows, "
@@ -186,7 +223,7 @@ def teacher_forced(sd, d, ids, hip_hist, hip_trace, noise_log=None, states=None,
         full = full.reshape(B, L)
         key = full
         if alg_temp > 0:
-            key = torch.softmax(full / alg_temp, -1) / sel_noise[i].float()
+            key = torch.softmax(full / alg_temp, -1) / sel_noise[step_indices[i] if step_indices is not None else i].float()
             key = key.masked_fill(~cand, -torch.inf)
         expect = prev.clone()
         x0_full = torch.full((B * L,), -1, dtype=torch.long)

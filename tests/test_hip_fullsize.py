@@ -23,20 +23,8 @@ L = P + G
 
 
 @pytest.fixture(scope="module")
-def full():
-    cfg = CoDAConfig()
-    assert (cfg.num_hidden_layers, cfg.vocab_size, cfg.hidden_size) == (28, 151936, 2048)
-    torch.manual_seed(4321)
-    old = torch.get_default_dtype()
-    torch.set_default_dtype(torch.bfloat16)
-    try:
-        with torch.device(DEV):
-            m = CoDALanguageModel(cfg)
-    finally:
-        torch.set_default_dtype(old)
-    m.eval()
-    with torch.no_grad():
-        m.lm_head.weight.mul_(8.0)
+def full(full_model):
+    cfg, m = full_model
     g = torch.Generator().manual_seed(1002)
     ids = torch.randint(0, 151643, (B, P), generator=g)
     trace = []
@@ -111,7 +99,7 @@ def test_c2_last_layer_compact_tail_equals_full_forward(full):
 
 
 def test_c2_teacher_forced_sample_vs_cpu_oracle(full):
-    from parity import describe, teacher_forced
+    from parity import describe, subsample, teacher_forced
     cfg, m, ids, seq, hist, trace = full
     d = ref_cpu.Dims()
     assert (d.vocab, d.hidden, d.layers, d.mask_id) == (cfg.vocab_size, cfg.hidden_size, cfg.num_hidden_layers, cfg.mask_token_id)
@@ -119,21 +107,7 @@ def test_c2_teacher_forced_sample_vs_cpu_oracle(full):
     rows = [0, 21]
     steps = [0, 1, 15, 16, 63, 112, 127]                               # block starts / ends, middle, last
     x_init = F.pad(ids, (0, G), value=cfg.mask_token_id)
-    states = [(x_init if i == 0 else hist[i - 1])[rows] for i in steps]
-    sub_hist = [hist[i][rows] for i in steps]
-    sub_trace = []
-    for i in steps:
-        t = trace[i]
-        n = int(t["count"].item())
-        dst = t["dst"][:n].long().cpu()
-        conf, x0 = t["conf"].cpu(), t["x0"].cpu()
-        keep = [k for k in range(n) if int(dst[k]) // L in rows]
-        new_dst = torch.tensor([rows.index(int(dst[k]) // L) * L + int(dst[k]) % L for k in keep], dtype=torch.int32)
-        c2 = torch.zeros(len(rows) * L)
-        z2 = torch.zeros(len(rows) * L, dtype=torch.int64)
-        c2[new_dst.long()] = conf[dst[keep]]
-        z2[new_dst.long()] = x0[dst[keep]]
-        sub_trace.append(dict(count=torch.tensor([len(keep)]), dst=new_dst, conf=c2, x0=z2))
+    states, sub_hist, sub_trace = subsample(x_init, hist, trace, rows, steps)
     stats, tr = teacher_forced(sd, d, ids[rows], sub_hist, sub_trace, states=states, step_indices=steps,
                                max_new_tokens=G, steps=STEPS, alg="entropy", block_length=BL)
     print(f"full-size teacher-forced sample (rows {rows}, steps {steps}): {describe(stats)}")
@@ -156,6 +130,24 @@ def test_full_architecture_stochastic_configs_teacher_forced(full, name, cfg, bl
     from test_hip_e2e import Replay
     cfg_m, m, _, _, _, _ = full
     d = ref_cpu.Dims()
+    # T = 0.1 amplifies a bf16 logit ulp ten times: with the lm_head x 8 "peaked" weights (|logit| ~ 60, ulp 0.25) the
+    # honest band would be e^13, i.e. no check at all.  This case runs on the unscaled lm_head (|logit| < 8; the
+    # division by 8 is exact in bf16 and is undone afterwards), where the band is that of a real checkpoint's logits.
+    rescale = name == "E1-like"
+    if rescale:
+        with torch.no_grad():
+            m.lm_head.weight.mul_(0.125)
+    try:
+        _stochastic_case(cfg_m, m, d, name, cfg, block)
+    finally:
+        if rescale:
+            with torch.no_grad():
+                m.lm_head.weight.mul_(8.0)
+
+
+def _stochastic_case(cfg_m, m, d, name, cfg, block):
+    from parity import describe, teacher_forced
+    from test_hip_e2e import Replay
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(99)
     ids = torch.randint(0, 151643, (2, 24), generator=g)

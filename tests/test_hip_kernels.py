@@ -410,15 +410,7 @@ def test_select_unmask_matches_oracle(alg_temp):
         assert torch.equal(xd.cpu(), expect), trial
 
 
-def hash_uniform_host(seed: int, rowkey: torch.Tensor, v: int) -> torch.Tensor:
-    """Host restatement of coda_hash_uniform (csrc/coda_common.h): uniform in (0, 1) from (seed, row key, index)."""
-    M = 0xFFFFFFFF
-    lo, hi = seed & M, (seed >> 32) & M
-    h = ((v * 0x9E3779B1) & M) ^ ((rowkey.to(torch.int64) * 0x85EBCA77) & M) ^ lo
-    h = h ^ (h >> 16); h = (h * 0x85EBCA6B) & M; h = h ^ (h >> 13); h = (h * 0xC2B2AE35) & M; h = h ^ (h >> 16)
-    h = (h + hi) & M
-    h = h ^ (h >> 15); h = (h * 0x2C1B3C6D) & M; h = h ^ (h >> 12); h = (h * 0x297A2D39) & M; h = h ^ (h >> 15)
-    return ((h >> 8).to(torch.float32) + 0.5) * (1.0 / 16777216.0)
+from parity import hash_uniform_host  # noqa: E402  (host restatement of coda_hash_uniform)
 
 
 def test_select_unmask_in_kernel_noise_matches_host_hash():
