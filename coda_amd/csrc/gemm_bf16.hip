@@ -830,6 +830,201 @@ static int launch256x128p(GemmArgs a, hipStream_t s) {
     return CODA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Persistent 256x256 (192x256) engine with FOUR waves, one per SIMD ("w4"): wave tile 128 (96) tokens x 128
+// features, 256 (192) accumulator registers per lane out of the 512 a lone wave on a SIMD may hold.
+//
+// Why: with 8 waves the wave tile is 128 x 64 and every K tile costs 8 waves x 24 KB = 192 KB of LDS fragment reads
+// per 2048 MFMA cycles; a 128 x 128 wave tile needs 4 x 32 KB = 128 KB for the same MFMAs (the fragment of one
+// operand is reused by 8 MFMAs instead of 4), and no two waves compete for a SIMD's issue port.  This is the shape
+// the vendor library's 256x256x64 kernels use (4 waves, wave tile 8 x 8 MFMA tiles).
+//
+// LDS image, DMA pattern and MFMA orientation are those of gemm_tile256.h (128-byte rows, 16-byte chunks XOR-swizzled
+// with row & 7 on the DMA source side, weight fragment = MFMA operand A).  Two stages of one K tile (64 deep); the
+// flat stream of K tiles q = 0, 1, ... runs across output tiles (persistent), stage = q & 1:
+//     k-step 0 of q : 64 MFMAs on fragment set F0      | LDS reads: F1 <- k-step 1 of q      (stage q & 1)
+//     lgkmcnt(0), vmcnt(stores of a just-finished epilogue), s_barrier      -> stage q & 1 is dead, tile q+1 has landed
+//     k-step 1 of q : 64 MFMAs on F1                   | LDS-DMA of tile q+2 into stage q & 1, one X and one W piece per
+//                                                        group of 8 MFMAs; LDS reads: F0 <- k-step 0 of q+1
+// Every instruction that is not an MFMA is issued inside a group of 8 MFMAs (128 cycles of matrix pipe).
+namespace tile256w4 {
+template <int MT>                                       // token groups of 16 per wave: 8 -> 256-token tile, 6 -> 192
+struct Tile {
+    static constexpr int BM = 2 * MT * 16, BN = 256, BK = 64;
+    static constexpr int X_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
+    static constexpr int STAGE_BYTES = X_BYTES + W_BYTES;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;   // 128 / 112 KiB
+    static constexpr int X_DMA = BM / 32, W_DMA = 8;    // LDS-DMA instructions per wave and K tile (4 waves x 8 rows each)
+};
+__device__ __forceinline__ int dma_row(int i, int wave, int lane) { return (i * 4 + wave) * 8 + (lane >> 3); }
+}  // namespace tile256w4
+
+template <int EPI, int MT>
+__global__ __launch_bounds__(256, 1) void gemm256w4_bf16_kernel(GemmArgs a) {
+    using T = tile256w4::Tile<MT>;
+    if (a.m_count) {
+        a.M = min(a.M, a.m_count[0]);
+        if (a.M <= 0) return;
+        a.tiles_m = (a.M + T::BM - 1) / T::BM;
+    }
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = a.tiles_m * a.tiles_n;
+    const int G = gridDim.x;
+    const int slot = xcd_remap(blockIdx.x, G);
+    const int nk = a.K / T::BK;
+    constexpr int GROUP_M = 4;
+    const int per_group = GROUP_M * a.tiles_n;
+    auto coords = [&](int L, int& m0, int& n0) {
+        const int g = L / per_group, gm0 = g * GROUP_M;
+        const int gsz = min(a.tiles_m - gm0, GROUP_M);
+        m0 = (gm0 + (L % per_group) % gsz) * T::BM;
+        n0 = ((L % per_group) / gsz) * T::BN;
+    };
+    const int ch = tile256::dma_chunk(lane) * 16;
+    unsigned xoff[T::X_DMA], woff[T::W_DMA];
+    auto set_src = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < T::X_DMA; ++i)
+            xoff[i] = (unsigned)((size_t)min(m0 + tile256w4::dma_row(i, wave, lane), a.M - 1) * a.ldx_bytes + ch);
+#pragma unroll
+        for (int i = 0; i < T::W_DMA; ++i)
+            woff[i] = (unsigned)((size_t)min(n0 + tile256w4::dma_row(i, wave, lane), a.N - 1) * a.ldw_bytes + ch);
+    };
+    int Lc = slot;
+    if (Lc >= ntiles) return;
+    int cm0, cn0;
+    coords(Lc, cm0, cn0);
+    set_src(cm0, cn0);
+    // DMA cursor over the workgroup's flat stream of K tiles: (output tile dL, K tile dk) is the next one to stage
+    int dL = Lc, dk = 0;
+    size_t dkb = 0;                            // byte offset of K tile dk inside a row
+    // past the end of the stream the pieces keep re-reading the last valid K tile into a stage nobody reads again:
+    // no branch around the DMA instructions, and the vmcnt bookkeeping stays uniform
+    bool dma_live = true;
+    auto dma_piece_x = [&](int i, char* stage) { glds16(a.X + dkb + xoff[i], stage + (i * 4 + wave) * 1024); };
+    auto dma_piece_w = [&](int i, char* stage) { glds16(a.W + dkb + woff[i], stage + T::X_BYTES + (i * 4 + wave) * 1024); };
+    auto dma_advance = [&]() {
+        if (!dma_live) return;
+        dkb += T::BK * 2;
+        if (++dk == nk) {
+            dk = 0;
+            dkb = 0;
+            dL += G;
+            if (dL < ntiles) {
+                int m0, n0;
+                coords(dL, m0, n0);
+                set_src(m0, n0);
+            } else {
+                dma_live = false;
+            }
+        }
+    };
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+        for (int i = 0; i < T::X_DMA; ++i) dma_piece_x(i, lds + st * T::STAGE_BYTES);
+#pragma unroll
+        for (int i = 0; i < T::W_DMA; ++i) dma_piece_w(i, lds + st * T::STAGE_BYTES);
+        dma_advance();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int r16 = lane & 15, kq = lane >> 4, sw = lane & 7;
+    const int p0 = ((0 * 4 + kq) ^ sw) * 16, p1 = ((1 * 4 + kq) ^ sw) * 16;
+    const char* xs = lds + (wm * (T::BM / 2) + r16) * 128;
+    const char* ws = lds + T::X_BYTES + (wn * 128 + r16) * 128;
+    bf16x8_t fw[2][8], fx[2][MT];              // fragment sets F0 / F1: [set][nt] weights, [set][mt] activations
+    auto read_w = [&](int set, int g, const char* base, int pos) { fw[set][g] = *(const bf16x8_t*)(base + g * 2048 + pos); };
+    auto read_x = [&](int set, int g, const char* base, int pos) { fx[set][g] = *(const bf16x8_t*)(base + g * 2048 + pos); };
+#pragma unroll
+    for (int g = 0; g < 8; ++g) read_w(0, g, ws, p0);
+#pragma unroll
+    for (int g = 0; g < MT; ++g) read_x(0, g, xs, p0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+
+    // epilogue stores per wave and full tile (two 64-feature halves; see epilogue_wave)
+    constexpr int ST_NARROW = 2 * (EPI == EPI_SWIGLU ? 2 : 4) * MT;
+    constexpr int ST_WIDE = EPI == EPI_F32 ? ST_NARROW : ST_NARROW / 2;
+    int stores_in_flight = 0;
+    int cur = 0;                               // byte offset of the stage that holds the current K tile
+    for (; Lc < ntiles; Lc += G) {
+        coords(Lc, cm0, cn0);
+        f32x4_t acc[8][MT];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < nk; ++t) {
+            const int nxt = T::STAGE_BYTES - cur;
+            const char* xc = xs + cur;
+            const char* wc = ws + cur;
+            // ---- k-step 0: MFMAs on F0, reads of F1 (k-step 1 of this tile)
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                read_w(1, g, wc, p1);
+                if (g < MT) read_x(1, g, xc, p1);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][g], fx[0][i], acc[g][i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- every wave's reads of this stage have retired; the next K tile of the stream has landed (vmcnt retires
+            // in order: what may stay in flight is what was issued AFTER its DMA = a just-finished epilogue's stores)
+            // (the builtin form of s_waitcnt: the compiler's own counter model sees it and adds no lgkmcnt(0) of its own
+            // behind the next reads; simm16 = vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14)
+            {
+                constexpr int SN = ST_NARROW > 63 ? 63 : ST_NARROW, SW = ST_WIDE > 63 ? 63 : ST_WIDE;
+                const int stn = t == 0 ? stores_in_flight : 0;
+                if (stn == ST_NARROW) __builtin_amdgcn_s_waitcnt((SN & 15) | 0x70 | ((SN >> 4) << 14));
+                else if (stn == ST_WIDE) __builtin_amdgcn_s_waitcnt((SW & 15) | 0x70 | ((SW >> 4) << 14));
+                else __builtin_amdgcn_s_waitcnt(0x0070);
+                __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- k-step 1: MFMAs on F1, DMA of stream tile q+2 into this stage, reads of F0 (k-step 0 of the next tile)
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if (g < T::X_DMA) dma_piece_x(g, lds + cur);
+                dma_piece_w(g, lds + cur);
+                read_w(0, g, ws + nxt, p0);
+                if (g < MT) read_x(0, g, xs + nxt, p0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1][g], fx[1][i], acc[g][i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): F0 of the next K tile
+            __builtin_amdgcn_sched_barrier(0);
+            dma_advance();
+            cur = nxt;
+        }
+        const bool full = cm0 + T::BM <= a.M && cn0 + T::BN <= a.N;
+        const int mrow0 = cm0 + wm * (T::BM / 2), ncol0 = cn0 + wn * 128;
+        epilogue_tile<EPI, MT>(a, *(const f32x4_t(*)[4][MT])&acc[0], mrow0, ncol0, lane, full);
+        epilogue_tile<EPI, MT>(a, *(const f32x4_t(*)[4][MT])&acc[4], mrow0, ncol0 + 64, lane, full);
+        stores_in_flight = full ? (a.wide && EPI != EPI_F32 ? ST_WIDE : ST_NARROW) : 0;
+    }
+}
+
+template <int EPI, int MT>
+static int launch256w4(GemmArgs a, hipStream_t s) {
+    using T = tile256w4::Tile<MT>;
+    if (coda_ensure_dyn_lds((const void*)gemm256w4_bf16_kernel<EPI, MT>, T::LDS_BYTES) != CODA_OK) return CODA_ERR_LAUNCH;
+    const int n_cu = coda_device_cus();
+    a.tiles_m = (a.M + T::BM - 1) / T::BM;
+    a.tiles_n = (a.N + T::BN - 1) / T::BN;
+    const int grid = a.tiles_m * a.tiles_n < n_cu ? a.tiles_m * a.tiles_n : n_cu;
+    hipLaunchKernelGGL((gemm256w4_bf16_kernel<EPI, MT>), dim3(grid), dim3(256), T::LDS_BYTES, s, a);
+    CODA_CHECK_LAUNCH("gemm256w4_bf16");
+    return CODA_OK;
+}
+template <int EPI>
+static int launch256w4_8(GemmArgs a, hipStream_t s) { return launch256w4<EPI, 8>(a, s); }
+template <int EPI>
+static int launch256w4_6(GemmArgs a, hipStream_t s) { return launch256w4<EPI, 6>(a, s); }
+
 template <int EPI>
 static int launch192x256p(GemmArgs a, hipStream_t s) { return launch256p<EPI, 3>(a, s); }
 template <int EPI>
@@ -848,7 +1043,8 @@ extern "C" int coda_gemm_probe(void* buf) {
 
 // `forced` (the engine argument of coda_gemm_bf16_ex): 0 automatic, 1 128x128, 2 256x256 (one tile per workgroup),
 // 3 persistent 256x256, 4 persistent 256x128, 5 persistent 192x256 (3-stage weight ring), 6 persistent 192x256 with the
-// 3-stage ring on the activations, 7 persistent 256x256 with a 3-stage activation ring (160 KiB of LDS).
+// 3-stage ring on the activations, 7 persistent 256x256 with a 3-stage activation ring (160 KiB of LDS),
+// 8 / 9 four-wave persistent 256x256 / 192x256 (wave tile 128 / 96 tokens x 128 features, one wave per SIMD).
 // -> 0: 128x128 engine, otherwise the engine number above.  The choice is a pure function of the call's arguments.
 static int pick_engine(const GemmArgs& a, int forced) {
     if (a.x_rows) return 0;
@@ -882,7 +1078,7 @@ static int launch(const GemmArgs& a, hipStream_t s) {
 extern "C" int coda_gemm_bf16_ex(const void* X, long long ldx, const int* x_rows, const void* W, long long ldw,
                                  void* C, long long ldc, const void* R, long long ldr,
                                  int M, int N, int K, int epilogue, int forced_engine, int flags, void* stream) {
-    if (forced_engine < 0 || forced_engine > 7) return CODA_ERR_ARG;
+    if (forced_engine < 0 || forced_engine > 9) return CODA_ERR_ARG;
     if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0 || N % 4 != 0) return CODA_ERR_SHAPE;
     if (epilogue == EPI_SWIGLU && N % 32 != 0) return CODA_ERR_SHAPE;
     if (epilogue == EPI_RESIDUAL && R == nullptr) return CODA_ERR_ARG;
@@ -913,6 +1109,8 @@ extern "C" int coda_gemm_bf16_ex(const void* X, long long ldx, const int* x_rows
         case EPI_F32: return fn<EPI_F32>(a, s);                \
         default: return CODA_ERR_ARG;                          \
     }
+    if (engine == 9) { CODA_DISPATCH(launch256w4_6) }
+    if (engine == 8) { CODA_DISPATCH(launch256w4_8) }
     if (engine == 7) { CODA_DISPATCH(launch256px) }
     if (engine == 6) { CODA_DISPATCH(launch192x256px) }
     if (engine == 5) { CODA_DISPATCH(launch192x256p) }

@@ -24,9 +24,10 @@ def short(name):
     return name.split("(")[0].replace("void ", "")
 
 
-rows = list(csv.DictReader(open(os.path.join(src, "kt", "kt_kernel_stats.csv"))))
+kt = os.path.join(src, "kt", "kt_kernel_stats.csv")
+rows = list(csv.DictReader(open(kt))) if os.path.exists(kt) else []
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
+with open(os.path.join(dst, f"{tag}_kernel_stats.csv" if rows else os.devnull), "w") as f:
     f.write("kernel,calls,total_ms,avg_us,min_us,max_us,percent\n")
     for r in rows:
         if float(r["TotalDurationNs"]) / tot < 1e-4:
@@ -73,3 +74,48 @@ if os.path.exists(fp) and os.path.exists(wp):
         out["gate_up_kernel"] = max((k for k in traffic if k.startswith("gemm") and "_kernel<2" in k), key=lambda k: traffic[k]).split("|")[0]
     json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print("traffic:", {k: f"{v/1e6:.1f} MB" for k, v in list(traffic.items())[:12]})
+
+
+# ---- MFMA utilisation (tools/mfma_pmc.sh): per kernel, averaged over launches
+m1 = os.path.join(src, "pmc_mfma1", "m_counter_collection.csv")
+m2 = os.path.join(src, "pmc_mfma2", "m_counter_collection.csv")
+if os.path.exists(m1):
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    dur = defaultdict(lambda: [0.0, 0])
+    for path in (m1, m2):
+        if not os.path.exists(path):
+            continue
+        seen = set()
+        with open(path) as fh:
+            for r in csv.DictReader(fh):
+                k = short(r["Kernel_Name"]) + "|grid=" + r["Grid_Size"]
+                a = acc[k][r["Counter_Name"]]
+                a[0] += float(r["Counter_Value"])
+                a[1] += 1
+                did = (path, r.get("Dispatch_Id"))
+                if did not in seen and path == m1:
+                    seen.add(did)
+                    dur[k][0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+                    dur[k][1] += 1
+    names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVES", "SQ_INSTS_VALU_MFMA_MOPS_BF16",
+             "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES"]
+    util = {}
+    with open(os.path.join(dst, f"{tag}_mfma_pmc.csv"), "w") as f:
+        f.write("kernel|grid,launches,avg_us_under_pmc," + ",".join(names) + ",mfma_util(=MFMA_BUSY/(GUI_ACTIVE*1024 SIMDs)),lds_conflict_share(=BANK_CONFLICT/IDX_ACTIVE)\n")
+        for k in sorted(acc, key=lambda k: -dur[k][0]):
+            if not any(k.startswith(p) for p in ("gemm", "flash", "lmhead", "rmsnorm", "confidence")):
+                continue
+            v = {n: (acc[k][n][0] / acc[k][n][1] if acc[k][n][1] else float("nan")) for n in names}
+            u = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] * 1024) if v["GRBM_GUI_ACTIVE"] == v["GRBM_GUI_ACTIVE"] and v["GRBM_GUI_ACTIVE"] else float("nan")
+            c = v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"] if v["SQ_LDS_IDX_ACTIVE"] == v["SQ_LDS_IDX_ACTIVE"] and v["SQ_LDS_IDX_ACTIVE"] else float("nan")
+            util[k] = u
+            f.write(f"{k},{dur[k][1]},{dur[k][0]/max(dur[k][1],1):.1f}," + ",".join(f"{v[n]:.0f}" for n in names) + f",{u:.4f},{c:.4f}\n")
+    tj = os.path.join(dst, "traffic.json")
+    out = json.load(open(tj)) if os.path.exists(tj) else {}
+    gu = [k for k in util if k.startswith("gemm") and "_kernel<2" in k and util[k] == util[k]]
+    if gu:
+        best = max(gu, key=lambda k: dur[k][0])
+        out["gate_up_mfma_util"] = util[best]
+        out["gate_up_mfma_util_source"] = f"profiles/{tag}_mfma_pmc.csv ({best})"
+        json.dump(out, open(tj, "w"), indent=1)
+    print("mfma util:", {k.split("|")[0][:40]: round(u, 3) for k, u in list(util.items())[:10]})
