@@ -278,11 +278,13 @@ def main():
             line["kernels"] = summ
             dom = summ.get("gate_up")
             if dom:
-                traffic = None
+                traffic = mfma_busy = None
                 tpath = os.path.join(ROOT, "profiles", "traffic.json")
                 if os.path.exists(tpath):
-                    traffic = json.load(open(tpath)).get("gate_up_hbm_bytes_per_launch")
-                line["roofline"] = {"bound": "mfma", "kernel": "gemm256p_bf16_kernel<SWIGLU> (gate|up projection + SiLU*up, persistent 256x256 engine)",
+                    tj = json.load(open(tpath))
+                    traffic, mfma_busy = tj.get("gate_up_hbm_bytes_per_launch"), tj.get("gate_up_mfma_util")
+                line["roofline"] = {"bound": "mfma", "kernel": "gemm256w4_bf16_kernel<SWIGLU> (gate|up projection + SiLU*up, four-wave persistent 256x256 engine)",
+                                    "mfma_busy_pmc": mfma_busy,
                                     "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                     "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
                                     "avg_launch_ms": dom["avg_ms"], "flops_per_launch": dom["flops_per_launch"],

@@ -1058,7 +1058,9 @@ static int pick_engine(const GemmArgs& a, int forced) {
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     const long t128 = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
     const long t192 = (long)((a.M + 191) / 192) * ((a.N + 255) / 256);
-    if (a.N >= 256 && t256 >= 200 && fill(t256) >= 0.85) return 3;
+    // whole rounds of 256x256 tiles: the four-wave engine (one wave per SIMD, 128x128 wave tiles) is 2-5 % ahead of the
+    // eight-wave one on these shapes in one-process A/B (gate|up 416-436 vs 429-445 us, plain qkv 140-150 vs 148-157 us)
+    if (a.N >= 256 && t256 >= 200 && fill(t256) >= 0.85) return 8;
     // e.g. 12288 x 2048: 512 tiles = 2 full rounds.  The third ring stage goes to the activations: in the decoder
     // they are what the previous kernel just wrote (down_proj: 151 MB, beyond every cache), -4..5 % with cold operands
     if (a.N >= 256 && t192 >= 200 && fill(t192) >= 0.85) return 6;

@@ -64,7 +64,7 @@ int coda_gemm_bf16(const void* X, long long ldx, const int* x_rows, const void* 
  * tests; the product path calls coda_gemm_bf16 = engine 0, flags 0).  engine: 0 = automatic choice by shape,
  * 1 = 128x128, 2 = 256x256 one tile per workgroup, 3 = persistent 256x256, 4 = persistent 256x128, 5 / 6 = persistent
  * 192x256 with the 3-stage ring on the weights / the activations, 7 = persistent 256x256 with a 3-stage activation
- * ring.  flags: CODA_GEMM_NARROW_STORES = interior tiles store 8-byte pieces per lane instead of 16-byte pieces after
+ * ring, 8 / 9 = four-wave persistent 256x256 / 192x256 (one wave per SIMD, wave tile 128 / 96 tokens x 128 features).  flags: CODA_GEMM_NARROW_STORES = interior tiles store 8-byte pieces per lane instead of 16-byte pieces after
  * a v_permlane16_swap exchange.  Results are identical up to fp32 summation order. */
 #define CODA_GEMM_NARROW_STORES 1
 int coda_gemm_bf16_ex(const void* X, long long ldx, const int* x_rows, const void* W, long long ldw, void* C,

@@ -111,7 +111,7 @@ def test_gemm_engines_swiglu(variant):
 def test_gemm_ex_rejects_unknown_engine():
     X = torch.zeros(64, 64, device=DEV, dtype=BF)
     C = torch.zeros(64, 64, device=DEV, dtype=BF)
-    rc = _lib.load().coda_gemm_bf16_ex(_p(X), 64, None, _p(X), 64, _p(C), 64, None, 0, 64, 64, 64, 0, 9, 0, _s())
+    rc = _lib.load().coda_gemm_bf16_ex(_p(X), 64, None, _p(X), 64, _p(C), 64, None, 0, 64, 64, 64, 0, 12, 0, _s())
     assert rc == -4
 
 

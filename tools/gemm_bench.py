@@ -12,13 +12,25 @@ from coda_amd import _lib  # noqa: E402
 DEV = "cuda"
 BF = torch.bfloat16
 lib = _lib.load()
+# A/B ACROSS BUILDS in one process: ALT_LIB=path/to/other/libcoda_hip.so; variant + 1000 runs on that library
+ALT = {}
+for n_, key_ in ((1, "ALT_LIB"), (2, "ALT_LIB2"), (3, "ALT_LIB3")):   # variant + 1000 / 2000 / 3000
+    if os.environ.get(key_):
+        import ctypes
+        ALT[n_] = ctypes.CDLL(os.environ[key_])
+        ALT[n_].coda_gemm_bf16_ex.restype, ALT[n_].coda_gemm_bf16_ex.argtypes = _lib.SIGNATURES["coda_gemm_bf16_ex"]
 
 
 def run(X, W, C, R, epi, v=0):
     """v = engine number (coda_gemm_bf16_ex), + 100 = same engine with 8-byte epilogue stores."""
-    _lib.call("coda_gemm_bf16_ex", X.data_ptr(), X.stride(0), None, W.data_ptr(), W.stride(0), C.data_ptr(), C.stride(0),
-              None if R is None else R.data_ptr(), 0 if R is None else R.stride(0), X.shape[0], W.shape[0], X.shape[1], epi,
-              v % 100, _lib.GEMM_NARROW_STORES if v >= 100 else 0, torch.cuda.current_stream().cuda_stream)
+    args = (X.data_ptr(), X.stride(0), None, W.data_ptr(), W.stride(0), C.data_ptr(), C.stride(0),
+            None if R is None else R.data_ptr(), 0 if R is None else R.stride(0), X.shape[0], W.shape[0], X.shape[1], epi,
+            v % 100, _lib.GEMM_NARROW_STORES if (v % 1000) >= 100 else 0, torch.cuda.current_stream().cuda_stream)
+    if v >= 1000:
+        rc = ALT[v // 1000].coda_gemm_bf16_ex(*args)
+        assert rc == 0, rc
+    else:
+        _lib.call("coda_gemm_bf16_ex", *args)
 
 
 def main():
@@ -29,6 +41,8 @@ def main():
         shapes = [("plain12k", 12288, 2048, 0), ("plain12k_k8k", 12288, 8192, 0), ("swiglu_k8k", 12288, 8192, 2),
                   ("plain_n4k_k8k", 4096, 8192, 0)]
     torch.manual_seed(0)
+    if os.environ.get("GEMM_ONLY"):
+        shapes = [sh for sh in shapes if sh[0] in os.environ["GEMM_ONLY"].split(",")]
     for name, N, K, epi in shapes:
         X = torch.randn(M, K, device=DEV, dtype=torch.float32).to(BF)
         W = (torch.randn(N, K, device=DEV, dtype=torch.float32) * 0.02).to(BF)

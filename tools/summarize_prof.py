@@ -101,15 +101,15 @@ if os.path.exists(m1):
              "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES"]
     util = {}
     with open(os.path.join(dst, f"{tag}_mfma_pmc.csv"), "w") as f:
-        f.write("kernel|grid,launches,avg_us_under_pmc," + ",".join(names) + ",mfma_util(=MFMA_BUSY/(GUI_ACTIVE*1024 SIMDs)),lds_conflict_share(=BANK_CONFLICT/IDX_ACTIVE)\n")
+        f.write("kernel|grid,launches,avg_us_under_pmc," + ",".join(names) + ",mfma_util(=MFMA_BUSY/(GUI_ACTIVE/8 XCDs*1024 SIMDs)),lds_conflict_share(=BANK_CONFLICT/IDX_ACTIVE)\n")
         for k in sorted(acc, key=lambda k: -dur[k][0]):
             if not any(k.startswith(p) for p in ("gemm", "flash", "lmhead", "rmsnorm", "confidence")):
                 continue
             v = {n: (acc[k][n][0] / acc[k][n][1] if acc[k][n][1] else float("nan")) for n in names}
-            u = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] * 1024) if v["GRBM_GUI_ACTIVE"] == v["GRBM_GUI_ACTIVE"] and v["GRBM_GUI_ACTIVE"] else float("nan")
+            u = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] * 128)   # GUI_ACTIVE is summed over the 8 XCDs; MFMA_BUSY over the 1024 SIMDs if v["GRBM_GUI_ACTIVE"] == v["GRBM_GUI_ACTIVE"] and v["GRBM_GUI_ACTIVE"] else float("nan")
             c = v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"] if v["SQ_LDS_IDX_ACTIVE"] == v["SQ_LDS_IDX_ACTIVE"] and v["SQ_LDS_IDX_ACTIVE"] else float("nan")
             util[k] = u
-            f.write(f"{k},{dur[k][1]},{dur[k][0]/max(dur[k][1],1):.1f}," + ",".join(f"{v[n]:.0f}" for n in names) + f",{u:.4f},{c:.4f}\n")
+            f.write(f'"{k}",{dur[k][1]},{dur[k][0]/max(dur[k][1],1):.1f},' + ",".join(f"{v[n]:.0f}" for n in names) + f",{u:.4f},{c:.4f}\n")
     tj = os.path.join(dst, "traffic.json")
     out = json.load(open(tj)) if os.path.exists(tj) else {}
     gu = [k for k in util if k.startswith("gemm") and "_kernel<2" in k and util[k] == util[k]]
