@@ -58,6 +58,22 @@ __device__ __forceinline__ float coda_hash_uniform(unsigned int seed_lo, unsigne
     return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
 }
 
+// x / t for a loop-invariant divisor, correctly rounded like the IEEE quotient (what `logits / temperature` is in the
+// reference), in three operations instead of the ~12 of a full division: with rt = RN(1 / t) computed once on the host in
+// double, q0 = RN(x rt), r = x - q0 t (exact in one FMA), q1 = RN(q0 + r rt) is the correctly rounded quotient
+// (Markstein's division theorem; tests/test_host_logic.py checks it against exact rational arithmetic for every bf16 x
+// and the temperatures of the configurations).  Infinities pass through (a logits hook may ban tokens with -inf).
+__device__ __forceinline__ float coda_div_by(float x, float t, float rt) {
+    const float q0 = x * rt;
+    const float r = __builtin_fmaf(-q0, t, x);
+    const float q1 = __builtin_fmaf(r, rt, q0);
+    return __builtin_isinf(x) ? x : q1;
+}
+
+// Exponential race with coda_hash_uniform noise: key = logit - log(-log(u)), u in [2^-25, 1 - 2^-25], so the noise term
+// lies in [-2.86, 17.33]; an entry more than this far below a known lower bound of the winner's logit cannot win.
+#define CODA_RACE_WINDOW 20.5f
+
 // 16-byte asynchronous global -> LDS copy.  The LDS destination is wave-uniform base + lane*16.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const CODA_GLOBAL void*)gsrc, (CODA_LDS void*)lds_wave_base, 16, 0, 0);

@@ -12,7 +12,7 @@ struct ConfArgs {
     const char* logits; long long ld_b; int is_bf16;
     int N, V;
     const int* count; const int* dst_pos;
-    int alg; float temperature, top_p; int top_k;
+    int alg; float temperature, inv_temperature, top_p; int top_k;
     const float* noise; unsigned int seed_lo, seed_hi;
     int round_conf; float* conf; long long* x0;
 };
@@ -64,10 +64,10 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
         float x;
         if (a.is_bf16) {
             x = bf16_bits_to_f32(((const unsigned short*)rp)[v]);
-            if (sampled) x = round_bf16(__fdiv_rn(x, a.temperature));
+            if (sampled) x = round_bf16(coda_div_by(x, a.temperature, a.inv_temperature));
         } else {
             x = ((const float*)rp)[v];
-            if (sampled) x = __fdiv_rn(x, a.temperature);
+            if (sampled) x = coda_div_by(x, a.temperature, a.inv_temperature);
         }
         return x;
     };
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
     const int nvec = vec_ok ? V / per : 0;
     auto xform = [&](float x) -> float {
         if (!sampled) return x;
-        x = __fdiv_rn(x, a.temperature);
+        x = coda_div_by(x, a.temperature, a.inv_temperature);
         return a.is_bf16 ? round_bf16(x) : x;
     };
     auto for_each = [&](auto&& fn) {
@@ -154,9 +154,16 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
             __syncthreads();
             const unsigned int hi_mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
             for_each([&](int, float x) {
+                // Entries whose fixed-point mass is zero (x more than ~28 below the row maximum: e^-28 * 2^40 < 1) cannot
+                // move the threshold: the running mass crosses top_p * total at an entry with non-zero mass, every
+                // zero-mass entry sorts below it, and the tie count at the last level is taken at the threshold key
+                // itself.  On peaked rows (low temperature, trained models) that is nearly the whole vocabulary, and the
+                // two LDS atomics per entry are what this pass costs.
+                const unsigned long long ms = mass(x);
+                if (ms == 0ull) return;
                 const unsigned int k = key_of(x);
                 if ((k & hi_mask) == prefix) {
-                    atomicAdd(&hist_m[sub + ((k >> shift) & 255)], mass(x));
+                    atomicAdd(&hist_m[sub + ((k >> shift) & 255)], ms);
                     atomicAdd(&hist_i[sub + ((k >> shift) & 255)], 1);
                 }
             });
@@ -314,7 +321,10 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
         s += e * d;
         if (x == mx) { ++n_max; arg = min(arg, v); }
         else m2 = fmaxf(m2, x);
-        if (sampled) {
+        // In-kernel noise is bounded: u in [2^-25, 1 - 2^-25] gives -log q in [-2.86, 17.33], so the row maximum's key is at
+        // least mx - 2.86 and an entry more than 20.2 below the maximum can never win the race: no hash, no logs for it
+        // (on peaked rows that is nearly the whole vocabulary, and the race is what a sampled pass costs).
+        if (sampled && (a.noise || x >= mx - CODA_RACE_WINDOW)) {
             const float q = a.noise ? a.noise[(size_t)row * V + v] : -__logf(coda_hash_uniform(a.seed_lo, a.seed_hi, rowkey, (unsigned)v));
             const float key = x - __logf(q);
             if (key > bkey || (key == bkey && v < barg)) { bkey = key; bl = x; barg = v; }
@@ -358,7 +368,7 @@ extern "C" int coda_confidence_from_logits(const void* logits, long long ld, int
     ConfArgs a;
     a.logits = (const char*)logits; a.ld_b = ld * (is_bf16 ? 2 : 4); a.is_bf16 = is_bf16;
     a.N = N; a.V = V; a.count = count; a.dst_pos = dst_pos;
-    a.alg = alg; a.temperature = temperature; a.top_p = top_p; a.top_k = top_k;
+    a.alg = alg; a.temperature = temperature; a.inv_temperature = temperature > 0.f ? (float)(1.0 / (double)temperature) : 0.f; a.top_p = top_p; a.top_k = top_k;
     a.noise = noise; a.seed_lo = (unsigned int)seed; a.seed_hi = (unsigned int)(seed >> 32);
     a.round_conf = round_conf_bf16; a.conf = conf; a.x0 = x0;
     hipLaunchKernelGGL(confidence_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, a);

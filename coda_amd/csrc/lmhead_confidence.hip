@@ -60,7 +60,7 @@ struct LmArgs {
     const int* src_rows; const int* dst_pos; const int* count;
     const char* W; long long ldw_b;
     int V, H, alg;
-    float temperature;
+    float temperature, inv_temperature;
     const float* noise;
     unsigned int seed_lo, seed_hi;
     float* part;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void lmhead_partial_kernel(LmArgs a) {
                     for (int r = 0; r < 4; ++r) {
                         const int v = n0 + wn * 64 + nt * 16 + fq + r;
                         float x = round_bf16(acc[nt][mt][r]);
-                        if (sampled) x = round_bf16(__fdiv_rn(x, a.temperature));
+                        if (sampled) x = round_bf16(coda_div_by(x, a.temperature, a.inv_temperature));
                         if (v >= a.V) x = -INFINITY;
                         l[nt * 4 + r] = x;
                         if (x > s.m1) { s.m2 = s.m1; s.m1 = x; s.arg = v; }
@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void lmhead_partial_kernel(LmArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int v = n0 + wn * 64 + nt * 16 + fq + r;
-                            if (v < a.V && cand < n) {
+                            // s.m1 = the row's running maximum (this tile included): a lower bound of the final one
+                            if (v < a.V && cand < n && (a.noise || l[nt * 4 + r] >= s.m1 - CODA_RACE_WINDOW)) {
                                 float q;
                                 if (a.noise) q = a.noise[(size_t)cand * a.V + v];
                                 else q = -__logf(coda_hash_uniform(a.seed_lo, a.seed_hi, (unsigned)a.dst_pos[cand], (unsigned)v));
@@ -256,7 +257,8 @@ static int lmhead_launch(const void* hidden, long long ld_hidden, const int* src
     a.hidden = (const char*)hidden; a.ldh_b = ld_hidden * 2;
     a.src_rows = src_rows; a.dst_pos = dst_pos; a.count = count;
     a.W = (const char*)W; a.ldw_b = ldw * 2;
-    a.V = V; a.H = H; a.alg = alg; a.temperature = temperature; a.noise = noise;
+    a.V = V; a.H = H; a.alg = alg; a.temperature = temperature; a.inv_temperature = temperature > 0.f ? (float)(1.0 / (double)temperature) : 0.f;
+    a.noise = noise;
     a.seed_lo = (unsigned int)seed; a.seed_hi = (unsigned int)(seed >> 32);
     a.part = (float*)part;
     hipStream_t s = (hipStream_t)stream;

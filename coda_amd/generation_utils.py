@@ -346,6 +346,8 @@ class DLMGenerationMixin:
             else:
                 sel_noise = noise.select_noise(i, B, L) if a_temp > 0 else None
                 eng.select_unmask(x, lo, hi, ratios[j], last, a_temp, sel_noise, seed)
+                if call.debug_trace is not None:
+                    call.debug_trace[-1]["k"] = eng.k_out.clone()
 
             if tokens_hook is not None:
                 x = tokens_hook(i, x, logits)

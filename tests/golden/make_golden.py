@@ -371,8 +371,14 @@ MID_SHAPES = (dict(B=8, P=24, G=8, steps=2), dict(B=8, P=28, G=4, steps=2), dict
 # are the ORACLE's outputs (meta["source"] says so); the selection rule is the same
 WIN_SMALL_SHAPES = (dict(B=2, P=8, G=8, steps=4, block_length=4), dict(B=1, P=8, G=16, steps=8, block_length=8))
 WIN_MID_SHAPES = (dict(B=8, P=24, G=8, steps=4, block_length=4), dict(B=4, P=56, G=8, steps=4, block_length=4))
+# longer runs (16-32 new tokens in 8-16 steps): small windows keep every decision among few candidates, so well-posed
+# runs of a random-init model exist at these lengths (the non-windowed search found none at 16 tokens / 8 steps)
+WIN_LONG_SHAPES = (dict(B=1, P=16, G=16, steps=8, block_length=4), dict(B=1, P=16, G=32, steps=16, block_length=4),
+                   dict(B=2, P=16, G=16, steps=8, block_length=4), dict(B=1, P=16, G=32, steps=16, block_length=8),
+                   dict(B=1, P=24, G=24, steps=12, block_length=4))
 SEP_MODELS = {"small": (SMALL, 22, SEP_SHAPES), "mid": (MID, 31, MID_SHAPES),
-              "winsmall": (SMALL, 22, WIN_SMALL_SHAPES), "winmid": (MID, 31, WIN_MID_SHAPES)}
+              "winsmall": (SMALL, 22, WIN_SMALL_SHAPES), "winmid": (MID, 31, WIN_MID_SHAPES),
+              "winlongsmall": (SMALL, 22, WIN_LONG_SHAPES), "winlongmid": (MID, 31, WIN_LONG_SHAPES)}
 SEP_ALGS = ("entropy", "maskgit_plus", "topk_margin")
 
 

@@ -113,10 +113,68 @@ def test_golden_free_running(small, golden):
         ref = torch.from_numpy(golden[key + "_seq"])
         rate = (out.cpu() == ref)[:, meta["P"]:].float().mean().item()
         rates.append(rate)
-        print(f"golden {key} alg={meta['alg']} steps={meta['steps']}: token match {rate:.3f}")
+        # first step whose state differs from the reference's, and the share of identical step states
+        hout = m.diffusion_generate(ids.to(DEV), max_new_tokens=meta["G"], steps=meta["steps"], alg=meta["alg"],
+                                    mask_token_id=d.mask_id, round_conf_to="bf16", return_dict_in_generate=True, output_history=True)
+        ref_hist = torch.from_numpy(golden[key + "_hist"]).long()
+        same = [bool(torch.equal(h.cpu(), r)) for h, r in zip(hout.history, ref_hist)]
+        first = same.index(False) if False in same else None
+        print(f"golden {key} alg={meta['alg']} steps={meta['steps']}: token match {rate:.3f}; first diverging step "
+              f"{first if first is not None else 'none'} of {len(same)}, {sum(same)}/{len(same)} step states identical")
         assert out.shape == ref.shape and (out.cpu()[:, :meta["P"]] == ref[:, :meta["P"]]).all()
     # free-running bf16 vs bf16-on-another-device is tie-limited (F5); report, and require broad agreement
     assert np.mean(rates) > 0.7, rates
+
+
+def test_f9_argmax_is_mask_token_and_k_beyond_a_rows_candidates(small):
+    """SURVEY.md F9 (generation_utils.py:507-512,528-538), through the logits hook with canned logits:
+      (a) a position whose argmax IS the mask token is 'revealed' as mask, i.e. stays masked - same on both paths;
+      (b) k comes from the batch-mean mask count, so rows couple: k equals the reference's fp32 value at every step;
+      (c) DECLARED DEVIATION: when k exceeds a row's candidates the reference's topk runs into the -inf entries and
+          writes mask_id over that many already-revealed tokens (which ones is torch.topk's unspecified order among
+          equal keys); the HIP path reveals the row's candidates and touches nothing else.
+    Teacher-forced per step from the HIP path's states; the canned logits are peaked, so no decision is a near-tie."""
+    d, sd, m = small
+    B, P, G, steps = 2, 4, 12, 6
+    L, V = P + G, d.vocab
+    g = torch.Generator().manual_seed(91)
+    table = torch.randn(B, L, V, generator=g) * 6.0
+    table[:, :, d.mask_id] = -30.0
+    stuck = [5, 7, 8, 11]                                   # row 0: argmax = mask token, and the most confident rows
+    for p in stuck:
+        table[0, p] = -20.0
+        table[0, p, d.mask_id] = 20.0
+    ids = torch.randint(0, d.pad_id, (B, P), generator=g)
+
+    def hook(step, x, logits):
+        return table.to(logits.device)
+    kw = dict(max_new_tokens=G, steps=steps, alg="entropy")
+    trace = []
+    out = m.diffusion_generate(ids.to(DEV), mask_token_id=d.mask_id, generation_logits_hook_func=hook,
+                               return_dict_in_generate=True, output_history=True, debug_trace=trace, **kw)
+    hist = [h.cpu() for h in out.history]
+    x_init = torch.nn.functional.pad(ids, (0, G), value=d.mask_id)
+    states = [x_init] + hist[:-1]
+    args = ref_cpu.SamplerArgs(max_length=L, steps=steps, mask_id=d.mask_id, alg="entropy")
+    tr = ref_cpu.sample_loop(lambda x: table, ids, args, logits_hook=lambda i, x, lg: table, trace=True, force_states=states)
+    remasked_total = 0
+    for i in range(steps):
+        prev, hip, ora = states[i], hist[i], tr.history[i]
+        was_mask = prev == d.mask_id
+        assert int(trace[i]["k"].item()) == tr.k[i], (i, int(trace[i]["k"].item()), tr.k[i])               # (b)
+        assert torch.equal(hip[was_mask], ora[was_mask]), i                                               # reveals identical
+        assert (hip[0, stuck] == d.mask_id).all()                                                           # (a)
+        assert torch.equal(hip[~was_mask], prev[~was_mask]), i                                              # HIP never touches a revealed token
+        changed = (~was_mask) & (ora != prev)
+        assert (ora[changed] == d.mask_id).all()
+        for b in range(B):
+            excess = max(0, tr.k[i] - int(was_mask[b].sum()))
+            assert int(changed[b].sum()) == excess, (i, b, int(changed[b].sum()), excess)                  # (c)
+        remasked_total += int(changed.sum())
+    print(f"F9 case: k per step {tr.k}; the reference re-masked {remasked_total} revealed tokens over the run (declared deviation), "
+          f"stuck positions still masked at the end: {int((hist[-1][0, stuck] == d.mask_id).sum())}/4")
+    assert remasked_total > 0, "the case never drove k beyond a row's candidates"
+    assert (hist[-1][1] != d.mask_id).all()
 
 
 def test_separated_golden_free_running_token_exact(small, mid, separated):

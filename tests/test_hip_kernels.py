@@ -701,3 +701,33 @@ def test_confidence_top_p_tie_cut_negative_threshold(scale, top_p):
     ent_ref = (pr * torch.log(pr + 1e-10)).sum(-1)
     conf_e, _ = _conf_logits(logits, 2, 0.0, top_p, 0)
     assert (conf_e.double() - ent_ref).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize("scale", [1.0, 12.0])
+def test_in_kernel_token_noise_race_matches_host_hash(scale):
+    """temperature > 0 with noise == NULL: x0 = argmax(l / T - log(-log u)), u = coda_hash_uniform(seed, row key, v).  The
+    kernels skip the hash for entries more than CODA_RACE_WINDOW below the row maximum (they cannot win); the host
+    restatement races over EVERY entry: same winners, on flat and on peaked rows, unfused and fused path."""
+    g = torch.Generator().manual_seed(71)
+    N, V, H, T, seed = 24, 4096, 128, 0.7, 0x0123_4567_89AB_CDEF
+    hidden = torch.randint(-2, 3, (N, H), generator=g).to(BF)
+    W = (torch.randint(-2, 3, (V, H), generator=g).float() * scale / 8).to(BF)       # exact products: identical logits on both paths
+    logits = (hidden.float() @ W.float().t()).to(BF)
+    u = hash_uniform_host(seed, torch.arange(N)[:, None], torch.arange(V)[None, :])
+    lt = (logits.float() / T).to(BF).float()
+    key = lt - torch.log(-torch.log(u))
+    want = key.argmax(-1)
+    top2 = key.topk(2, -1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-3                                        # device __logf vs host log
+    conf = torch.full((N,), float("nan"), device=DEV)
+    x0 = torch.full((N,), -1, device=DEV, dtype=torch.int64)
+    ld = logits.to(DEV)
+    _lib.call("coda_confidence_from_logits", _p(ld), V, 1, N, V, None, None, 0, T, 0.0, 0, None, seed, 0, _p(conf), _p(x0), _s())
+    torch.cuda.synchronize()
+    assert torch.equal(x0.cpu()[clear], want[clear]) and clear.sum() >= N - 2
+    p = torch.softmax(lt, -1)
+    assert (conf.cpu()[clear] - p[torch.arange(N), want][clear]).abs().max() < 2e-3
+    src = torch.arange(N, dtype=torch.int32)
+    c2, z2 = _lmhead(hidden.to(DEV), W.to(DEV), src.to(DEV), src.to(DEV), torch.tensor([N], dtype=torch.int32).to(DEV), 128, 0,
+                     temperature=T, T_total=N, seed=seed)
+    assert torch.equal(z2.cpu()[clear], want[clear])

@@ -246,3 +246,43 @@ def test_bench_spawns_its_own_ranks_and_gathers_metrics():
                         "--new-tokens", "8", "--denoise-steps", "4", "--block-length", "4"],
                        env=dict(env, CODA_BENCH_TEST_FAIL_RANK="1"), capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "stub rank asked to fail" in r.stderr
+
+
+def test_three_operation_division_is_correctly_rounded():
+    """coda_div_by (csrc/coda_common.h): q0 = RN(x rt), r = fma(-q0, t, x), q1 = fma(r, rt, q0) with rt = RN(1 / t) must equal
+    the IEEE fp32 quotient x / t (the reference's `logits / temperature`) for EVERY bf16 x; checked in exact rational
+    arithmetic (each fp32 operation = one rounding of an exact value)."""
+    from fractions import Fraction
+    import numpy as np
+
+    def rn32(fr):                       # exact Fraction -> nearest float32 (ties to even), as a Fraction
+        if fr == 0:
+            return Fraction(0)
+        sign = -1 if fr < 0 else 1
+        a = abs(fr)
+        e = a.numerator.bit_length() - a.denominator.bit_length()
+        if Fraction(2) ** e > a:
+            e -= 1
+        e = max(e, -126)
+        scaled = a / Fraction(2) ** (e - 23)          # in [2^23, 2^24) for normal numbers
+        n = scaled.numerator // scaled.denominator
+        rem = scaled - n
+        if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and n % 2 == 1):
+            n += 1
+        return sign * n * Fraction(2) ** (e - 23)
+    bits = np.arange(65536, dtype=np.uint32)
+    xs = (bits << 16).view(np.float32)
+    xs = xs[np.isfinite(xs) & (np.abs(xs) < 1e30) & ((np.abs(xs) > 1e-30) | (xs == 0))]     # where x / t stays normal
+    xs = xs[::7]                                      # every 7th bf16 value (odd stride: all mantissa patterns), ~9000 points
+    for t in (0.1, 0.7, 0.5, 0.8, 1.3, 0.6):
+        t32 = Fraction(float(np.float32(t)))
+        rt = rn32(1 / t32)
+        assert float(rt) == float(np.float32(1.0 / float(np.float32(t))))                     # the host's (float)(1.0 / (double)t)
+        bad = 0
+        for x in xs:
+            xf = Fraction(float(x))
+            q0 = rn32(xf * rt)
+            r = rn32(xf - q0 * t32)
+            q1 = rn32(q0 + r * rt)
+            bad += q1 != rn32(xf / t32)
+        assert bad == 0, (t, bad)

@@ -22,6 +22,11 @@ with torch.no_grad():
 
 # name, B, P, G, total steps, block, extra kwargs, steps actually run (a whole number of blocks)
 CONFIGS = [
+    # B = 1: the reference's CPU-runnable case on the GPU, and the FastAPI service's defaults (config.py:35-42: 256 tokens,
+    # 128 steps, entropy, alg_temp 0.1; block_length read but never passed on - SURVEY F2).  Weight-stream floor:
+    # 4.06 GB of bf16 parameters / 8 TB/s = 0.51 ms per denoise step
+    ("C1 on GPU (B=1)", 1, 128, 256, 128, 32, dict(alg="entropy"), 32),
+    ("serving default (B=1)", 1, 128, 256, 128, None, dict(alg="entropy", alg_temp=0.1), 16),
     ("C2 window", 32, 128, 256, 128, 32, dict(alg="entropy"), 16),
     ("C2 reference", 32, 128, 256, 128, None, dict(alg="entropy"), 8),
     ("C3/GPU window", 64, 512, 256, 128, 32, dict(alg="entropy"), 16),
