@@ -19,6 +19,7 @@ struct GemmArgs {
     int M, N, K;
     int tiles_m, tiles_n;
     int wide;                       // C (and R) rows are 16-byte aligned: interior tiles may use 16-byte stores / residual loads
+    int ksplit; long long slab_bytes;   // 128x128 engine only: K is cut into ksplit ranges, range s writes fp32 partials to C + s * slab_bytes
 #ifdef CODA_CLOCK_PROBE
     unsigned long long* probe;      // diagnostic build only: per-workgroup (d s_memtime, d s_memrealtime)
 #endif
@@ -191,8 +192,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
 
     // XCD-aware + grouped tile order: consecutive ids within an XCD chunk walk 8 row-tiles of one
     // column-tile group, so the W panel and the X panels stay hot in that XCD's L2.
-    const int nwg = a.tiles_m * a.tiles_n;
-    const int id = xcd_remap(blockIdx.x, nwg);
+    const int ntile = a.tiles_m * a.tiles_n;
+    const int nwg = ntile * a.ksplit;
+    int id = xcd_remap(blockIdx.x, nwg);
+    // split-K (small M: too few tiles to engage the chip, and every CU's load path takes only 64 B/clk): K range ks of
+    // tile id; the ranges of one tile are neighbours in the id order, so its X / W panels are read on one XCD
+    const int ks = id % a.ksplit;
+    id /= a.ksplit;
     constexpr int GROUP_M = 8;
     const int per_group = GROUP_M * a.tiles_n;
     const int g = id / per_group;
@@ -205,6 +211,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
         a.M = min(a.M, a.m_count[0]);
         if (m0 >= a.M) return;
     }
+    const int kc = a.K / a.ksplit;            // host guarantees kc % BK == 0
+    a.X += (size_t)ks * kc * 2;
+    a.W += (size_t)ks * kc * 2;
+    a.C += (size_t)ks * a.slab_bytes;
+    a.K = kc;
 
     Frag f;
     const int ch = dma_chunk(lane) * 16;
@@ -1072,7 +1083,7 @@ static int pick_engine(const GemmArgs& a, int forced) {
 template <int EPI>
 static int launch(const GemmArgs& a, hipStream_t s) {
     if (coda_ensure_dyn_lds((const void*)gemm_bf16_kernel<EPI>, LDS_BYTES) != CODA_OK) return CODA_ERR_LAUNCH;
-    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(256), LDS_BYTES, s, a);
+    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(256), LDS_BYTES, s, a);
     CODA_CHECK_LAUNCH("gemm_bf16");
     return CODA_OK;
 }
@@ -1090,6 +1101,7 @@ extern "C" int coda_gemm_bf16_ex(const void* X, long long ldx, const int* x_rows
     if (((uintptr_t)C) & (4 * esz - 1) || (ldc * esz) % (4 * esz)) return CODA_ERR_ALIGN;
     if (R && ((((uintptr_t)R) & 7) || (ldr * 2) % 8)) return CODA_ERR_ALIGN;
     GemmArgs a{};
+    a.ksplit = 1;
     a.X = (const char*)X; a.ldx_bytes = ldx * 2; a.x_rows = x_rows;
     a.W = (const char*)W; a.ldw_bytes = ldw * 2;
     a.C = (char*)C; a.ldc_bytes = ldc * esz;
@@ -1145,6 +1157,7 @@ extern "C" int coda_gemm_bf16_counted(const void* X, long long ldx, const int* m
     if (((uintptr_t)X | (uintptr_t)W) & 15 || (ldx * 2) % 16 || (ldw * 2) % 16) return CODA_ERR_ALIGN;
     if (((uintptr_t)C) & 7 || (ldc * 2) % 8) return CODA_ERR_ALIGN;
     GemmArgs a{};
+    a.ksplit = 1;
     a.X = (const char*)X; a.ldx_bytes = ldx * 2; a.x_rows = nullptr; a.m_count = m_count;
     a.W = (const char*)W; a.ldw_bytes = ldw * 2;
     a.C = (char*)C; a.ldc_bytes = ldc * 2;
@@ -1172,6 +1185,7 @@ extern "C" int coda_qkv_proj_rope(const void* X, long long ldx, const void* W, l
         return CODA_ERR_ALIGN;
     if ((size_t)T * ldx * 2 >= 0xffffffffull || (size_t)N * ldw * 2 >= 0xffffffffull) return CODA_ERR_SHAPE;
     GemmArgs a{};
+    a.ksplit = 1;
     a.X = (const char*)X; a.ldx_bytes = ldx * 2; a.x_rows = nullptr;
     a.W = (const char*)W; a.ldw_bytes = ldw * 2;
     a.C = (char*)qkv; a.ldc_bytes = ld * 2;
@@ -1182,4 +1196,81 @@ extern "C" int coda_qkv_proj_rope(const void* X, long long ldx, const void* W, l
     a.rope_cos = (const char*)cos; a.rope_sin = (const char*)sin;
     a.L = L; a.q_feat = n_q * 128; a.qk_feat = (n_q + n_kv) * 128; a.eps = eps;
     return launch256p<EPI_QKROPE>(a, (hipStream_t)stream);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Split-K for small M (the B = 1 serving shape): at M = 384 a projection has 48-96 tiles of 128x128, so 48-96 of the 256
+// CUs do all the loading, each through a 64 B/clk load path - the launch is bound by how many CUs take part, not by HBM.
+// The K range is cut into `ksplit` pieces (ksplit x more workgroups, each loading 1 / ksplit as much), fp32 partial tiles go
+// to a caller workspace, and this kernel sums them in a fixed order (deterministic) and applies the epilogue with the
+// reference's rounding points (projection -> bf16, then residual add / SiLU * up).
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ part, long long slab_floats, int ksplit,
+                                                              int M, int N, char* __restrict__ C, long long ldc_bytes,
+                                                              const char* __restrict__ R, long long ldr_bytes) {
+    const int ncol4 = (EPI == EPI_SWIGLU ? N / 2 : N) / 4;            // 4 output columns per thread
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * ncol4) return;
+    const int m = (int)(idx / ncol4), j = (int)(idx % ncol4) * 4;
+    if constexpr (EPI == EPI_SWIGLU) {
+        // weight rows are interleaved in blocks of 16: [gate 16 | up 16]
+        const int gcol = 32 * (j / 16) + (j % 16);
+        f32x4_t gsum = {0.f, 0.f, 0.f, 0.f}, usum = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < ksplit; ++s) {
+            const float* p = part + (size_t)s * slab_floats + (size_t)m * N + gcol;
+            gsum += *(const f32x4_t*)p;
+            usum += *(const f32x4_t*)(p + 16);
+        }
+        const unsigned g01 = pack_bf16x2(gsum[0], gsum[1]), g23 = pack_bf16x2(gsum[2], gsum[3]);
+        const unsigned u01 = pack_bf16x2(usum[0], usum[1]), u23 = pack_bf16x2(usum[2], usum[3]);
+        float s0 = silu_f32(bf16_lo(g01)), s1 = silu_f32(bf16_hi(g01)), s2 = silu_f32(bf16_lo(g23)), s3 = silu_f32(bf16_hi(g23));
+        round_bf16_pair(s0, s1);
+        round_bf16_pair(s2, s3);
+        *(u32x2_t*)(C + (size_t)m * ldc_bytes + (size_t)j * 2) =
+            (u32x2_t){pack_bf16x2(s0 * bf16_lo(u01), s1 * bf16_hi(u01)), pack_bf16x2(s2 * bf16_lo(u23), s3 * bf16_hi(u23))};
+    } else {
+        f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < ksplit; ++s) sum += *(const f32x4_t*)(part + (size_t)s * slab_floats + (size_t)m * N + j);
+        unsigned v0 = pack_bf16x2(sum[0], sum[1]), v1 = pack_bf16x2(sum[2], sum[3]);
+        if constexpr (EPI == EPI_RESIDUAL) {
+            const u32x2_t r = *(const u32x2_t*)(R + (size_t)m * ldr_bytes + (size_t)j * 2);
+            v0 = pack_bf16x2(bf16_lo(v0) + bf16_lo(r[0]), bf16_hi(v0) + bf16_hi(r[0]));
+            v1 = pack_bf16x2(bf16_lo(v1) + bf16_lo(r[1]), bf16_hi(v1) + bf16_hi(r[1]));
+        }
+        *(u32x2_t*)(C + (size_t)m * ldc_bytes + (size_t)j * 2) = (u32x2_t){v0, v1};
+    }
+}
+
+extern "C" int coda_gemm_bf16_splitk(const void* X, long long ldx, const void* W, long long ldw, void* C, long long ldc,
+                                     const void* R, long long ldr, int M, int N, int K, int epilogue, int ksplit,
+                                     void* workspace, long long workspace_bytes, void* stream) {
+    if (ksplit <= 1) return coda_gemm_bf16(X, ldx, nullptr, W, ldw, C, ldc, R, ldr, M, N, K, epilogue, stream);
+    if (M <= 0 || N <= 0 || K <= 0 || N % 32 != 0 || K % ksplit != 0 || (K / ksplit) % BK != 0) return CODA_ERR_SHAPE;
+    if (epilogue != EPI_PLAIN && epilogue != EPI_RESIDUAL && epilogue != EPI_SWIGLU) return CODA_ERR_ARG;
+    if (epilogue == EPI_RESIDUAL && R == nullptr) return CODA_ERR_ARG;
+    if (!X || !W || !C || !workspace) return CODA_ERR_ARG;
+    if ((long long)ksplit * M * N * 4 > workspace_bytes) return CODA_ERR_SHAPE;
+    if (((uintptr_t)X | (uintptr_t)W | (uintptr_t)workspace) & 15 || (ldx * 2) % 16 || (ldw * 2) % 16) return CODA_ERR_ALIGN;
+    if (((uintptr_t)C & 7) || (ldc * 2) % 8 || (R && ((((uintptr_t)R) & 7) || (ldr * 2) % 8))) return CODA_ERR_ALIGN;
+    GemmArgs a{};
+    a.X = (const char*)X; a.ldx_bytes = ldx * 2; a.x_rows = nullptr;
+    a.W = (const char*)W; a.ldw_bytes = ldw * 2;
+    a.C = (char*)workspace; a.ldc_bytes = (long long)N * 4;
+    a.M = M; a.N = N; a.K = K;
+    a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
+    a.wide = 0;
+    a.ksplit = ksplit; a.slab_bytes = (long long)M * N * 4;
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = launch<EPI_F32>(a, s);
+    if (rc != CODA_OK) return rc;
+    const long long threads = (long long)M * ((epilogue == EPI_SWIGLU ? N / 2 : N) / 4);
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    const float* part = (const float*)workspace;
+    const long long slab = (long long)M * N;
+    if (epilogue == EPI_SWIGLU) hipLaunchKernelGGL(splitk_epilogue_kernel<EPI_SWIGLU>, grid, dim3(256), 0, s, part, slab, ksplit, M, N, (char*)C, ldc * 2, (const char*)R, ldr * 2);
+    else if (epilogue == EPI_RESIDUAL) hipLaunchKernelGGL(splitk_epilogue_kernel<EPI_RESIDUAL>, grid, dim3(256), 0, s, part, slab, ksplit, M, N, (char*)C, ldc * 2, (const char*)R, ldr * 2);
+    else hipLaunchKernelGGL(splitk_epilogue_kernel<EPI_PLAIN>, grid, dim3(256), 0, s, part, slab, ksplit, M, N, (char*)C, ldc * 2, (const char*)R, ldr * 2);
+    CODA_CHECK_LAUNCH("splitk_epilogue");
+    return CODA_OK;
 }

@@ -59,6 +59,23 @@ def permute_qk_rows(wqkv: torch.Tensor, n_q: int, n_kv: int, d: int = 128) -> to
     return wqkv[idx.to(wqkv.device)].contiguous()
 
 
+SPLITK_WS_BYTES = 32 << 20
+
+
+def splitk_factor(M: int, N: int, K: int, ws_bytes: int = SPLITK_WS_BYTES) -> int:
+    """K ranges for a projection at small M (coda_gemm_bf16_splitk).  A launch with fewer than ~160 tiles of 128 x 128 leaves
+    most CUs without work while the busy ones are bound by their own 64 B/clk load path; cutting K engages up to ~450
+    workgroups (two per CU).  Returns 1 when the plain engines fill the chip."""
+    tiles = -(-M // 128) * -(-N // 128)
+    if tiles >= 160 or M > 1024:          # measured at M = 384: gate|up (288 tiles) in two ranges is a loss (4.40 vs 3.81 ms per step)
+        return 1
+    best = 1
+    for s in range(2, max(1, 448 // tiles) + 1):
+        if K % s == 0 and (K // s) % 64 == 0 and K // s >= 256 and s * M * N * 4 <= ws_bytes:
+            best = s
+    return best
+
+
 class HipEngine:
     """One engine per model replica (per GPU)."""
 
@@ -157,8 +174,15 @@ class HipEngine:
         t = self.timer
         if t is not None:
             t.begin(name, 2.0 * M * N * K)
-        _lib.call("coda_gemm_bf16", _ptr(X), X.stride(0), _ptr(rows), _ptr(W), W.stride(0), _ptr(C), ldc,
-                  _ptr(R), 0 if R is None else R.stride(0), M, N, K, epi, self._stream())
+        ks = splitk_factor(M, N, K) if (rows is None and epi != _lib.EPI_F32 and N % 32 == 0) else 1
+        if ks > 1:
+            if getattr(self, "_splitk_ws", None) is None:
+                self._splitk_ws = torch.empty(SPLITK_WS_BYTES, device=self.device, dtype=torch.uint8)
+            _lib.call("coda_gemm_bf16_splitk", _ptr(X), X.stride(0), _ptr(W), W.stride(0), _ptr(C), ldc, _ptr(R),
+                      0 if R is None else R.stride(0), M, N, K, epi, ks, _ptr(self._splitk_ws), SPLITK_WS_BYTES, self._stream())
+        else:
+            _lib.call("coda_gemm_bf16", _ptr(X), X.stride(0), _ptr(rows), _ptr(W), W.stride(0), _ptr(C), ldc,
+                      _ptr(R), 0 if R is None else R.stride(0), M, N, K, epi, self._stream())
         if t is not None:
             t.end(name)
 
@@ -206,7 +230,9 @@ class HipEngine:
         scale = 1.0 / math.sqrt(self.d)
         for li, lw in enumerate(self.lw):
             _lib.call("coda_rmsnorm", _ptr(self.h), self.H, _ptr(lw["n_in"]), _ptr(self.a), self.H, T, self.H, self.eps, s)
-            if self.fuse_qk and T >= 256:
+            # the fused epilogue lives on the 256x256 persistent engine: below ~2048 tokens its 256-token tiles leave most
+            # of the chip idle (T = 384: 32 workgroups), and the deep-ring 128x128 engine + the standalone norm/rotary kernel win
+            if self.fuse_qk and T >= 2048:
                 t = self.timer
                 if t is not None:
                     t.begin("qkv", 2.0 * T * self.qkv_dim * self.H)

@@ -71,6 +71,16 @@ int coda_gemm_bf16_ex(const void* X, long long ldx, const int* x_rows, const voi
                       long long ldc, const void* R, long long ldr, int M, int N, int K, int epilogue, int engine,
                       int flags, void* stream);
 
+/* coda_gemm_bf16 for SMALL M (the B = 1 serving shape, M = 384; the compact last-layer tail): same result contract
+ * (CODA_EPI_PLAIN / RESIDUAL / SWIGLU; bf16 rounding points as above), computed as `ksplit` K ranges whose fp32 partial
+ * tiles go to `workspace` (ksplit * M * N * 4 bytes) and are summed in a fixed order by a second kernel (deterministic).
+ * Why: at M = 384 a projection has 48-96 tiles, so 48-96 of 256 CUs do all the loading; split-K engages the others.
+ * ksplit <= 1 forwards to coda_gemm_bf16.  K % ksplit == 0, (K / ksplit) % 64 == 0, N % 32 == 0.  The caller picks ksplit
+ * (coda_amd/engine.py::splitk_factor): the library keeps no heuristics state. */
+int coda_gemm_bf16_splitk(const void* X, long long ldx, const void* W, long long ldw, void* C, long long ldc,
+                          const void* R, long long ldr, int M, int N, int K, int epilogue, int ksplit, void* workspace,
+                          long long workspace_bytes, void* stream);
+
 /* q_norm / k_norm + rotary embedding, in place on the fused QKV activation.
  * Replaces modeling_coda.py:128-148 and modeling_utils.py:70-101.
  * qkv bf16 [T, (n_q + 2 n_kv) * 128]: q heads, then k heads, then v heads (v untouched).

@@ -115,6 +115,40 @@ def test_gemm_ex_rejects_unknown_engine():
     assert rc == -4
 
 
+@pytest.mark.parametrize("M,N,K,ks,epi", [(384, 2048, 2048, 8, "res"), (384, 4096, 2048, 4, "plain"), (384, 2048, 6144, 8, "res"),
+                                          (200, 256, 512, 2, "plain"), (1024, 2048, 6144, 3, "res"), (130, 384, 1024, 4, "swiglu")])
+def test_gemm_splitk_exact_integer(M, N, K, ks, epi):
+    """coda_gemm_bf16_splitk (small-M path): fp32 partials of the K ranges summed in a fixed order + the epilogue; integer
+    operands make every partial and their sum exact, so the result must equal the one-range engines bit for bit."""
+    from coda_amd.engine import interleave_gate_up, splitk_factor
+    X = int_mat((M, K), -3, 3, 61).to(DEV)
+    ws = torch.empty(ks * M * N * 4, device=DEV, dtype=torch.uint8)
+    if epi == "swiglu":
+        Wg, Wu = int_mat((N // 2, K), -1, 1, 62), int_mat((N // 2, K), -2, 2, 63)
+        W = interleave_gate_up(Wg, Wu).to(DEV)
+        want = gemm(X, W, _lib.EPI_SWIGLU, engine=1)
+        code, R, cols = _lib.EPI_SWIGLU, None, N // 2
+    else:
+        W = int_mat((N, K), -2, 2, 62).to(DEV)
+        R = int_mat((M, N), -50, 50, 63).to(DEV) if epi == "res" else None
+        code, cols = (_lib.EPI_RESIDUAL if epi == "res" else _lib.EPI_PLAIN), N
+        want = gemm(X, W, code, R=R, engine=1)
+    C = torch.full((M, cols), float("nan"), device=DEV, dtype=BF)
+    _lib.call("coda_gemm_bf16_splitk", _p(X), K, _p(W), K, _p(C), cols, _p(R), 0 if R is None else N, M, N, K, code, ks, _p(ws),
+              ws.numel(), _s())
+    torch.cuda.synchronize()
+    assert torch.equal(C, want)
+    # in place on the residual stream, as the decoder calls it
+    if epi == "res":
+        Rc = R.clone()
+        _lib.call("coda_gemm_bf16_splitk", _p(X), K, _p(W), K, _p(Rc), N, _p(Rc), N, M, N, K, code, ks, _p(ws), ws.numel(), _s())
+        torch.cuda.synchronize()
+        assert torch.equal(Rc, want)
+    assert splitk_factor(384, 2048, 2048) == 8 and splitk_factor(384, 12288, 2048) == 1 and splitk_factor(12288, 2048, 2048) == 1
+    lib = _lib.load()
+    assert lib.coda_gemm_bf16_splitk(_p(X), K, _p(W), K, _p(C), cols, _p(R), 0 if R is None else N, M, N, K, code, ks, _p(ws), 16, _s()) == -1
+
+
 def test_gemm_identity_asymmetric():
     K = 128
     X = torch.eye(K).to(BF)
