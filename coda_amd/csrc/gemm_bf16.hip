@@ -870,6 +870,111 @@ struct Tile {
 __device__ __forceinline__ int dma_row(int i, int wave, int lane) { return (i * 4 + wave) * 8 + (lane >> 3); }
 }  // namespace tile256w4
 
+// Fused q_norm / k_norm + rotary epilogue for the four-wave engine (modeling_coda.py:128-148, modeling_utils.py:70-101).
+// A wave's 128 features are exactly ONE head (tiles are 256 features wide and head_dim is 128), so everything a token
+// needs sits in the four lanes that share lane & 15: the RMS over the head is an in-lane sum plus two shuffles, and the
+// rotary partner of feature j = 16 nt + 4 (lane >> 4) + r is j + 64 = the same register of block nt + 4.  No LDS, no
+// partner wave, and the weight rows stay in their natural order.  Rounding points follow the reference's bf16 op
+// sequence: projection -> bf16; x * rsqrt(mean x^2 + eps) -> bf16; * norm weight -> bf16; the four rotary products ->
+// bf16 each; their sum / difference -> bf16.  V tiles take the plain epilogue.
+__device__ __forceinline__ void epilogue256w4_qkrope(const GemmArgs& a, const f32x4_t (&acc)[8][8], int mrow0, int ncol0, int lane,
+                                                     bool full) {
+    if (ncol0 >= a.qk_feat) {                 // V columns: tile-uniform branch
+        epilogue_tile<EPI_PLAIN, 8>(a, *(const f32x4_t(*)[4][8])&acc[0], mrow0, ncol0, lane, full);
+        epilogue_tile<EPI_PLAIN, 8>(a, *(const f32x4_t(*)[4][8])&acc[4], mrow0, ncol0 + 64, lane, full);
+        return;
+    }
+    const int tok = lane & 15, fq = (lane >> 4) * 4;
+    const char* nw = ncol0 < a.q_feat ? a.qn_w : a.kn_w;
+    const int mf = mrow0 + tok;
+    // norm weights of the lane's 2 x 16 features (first half nt 0..3, second half nt 4..7): loop-invariant over tokens
+    float w1[4][4], w2[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int j = nt * 16 + fq;
+        const u32x2_t a1 = *(const u32x2_t*)(nw + j * 2), a2 = *(const u32x2_t*)(nw + (j + 64) * 2);
+        w1[nt][0] = bf16_lo(a1[0]); w1[nt][1] = bf16_hi(a1[0]); w1[nt][2] = bf16_lo(a1[1]); w1[nt][3] = bf16_hi(a1[1]);
+        w2[nt][0] = bf16_lo(a2[0]); w2[nt][1] = bf16_hi(a2[0]); w2[nt][2] = bf16_lo(a2[1]); w2[nt][3] = bf16_hi(a2[1]);
+    }
+    const size_t rs = (size_t)16 * a.ldc_bytes;
+    const bool wide = full && a.wide;
+    char* ow = a.C + (size_t)mf * a.ldc_bytes + (size_t)ncol0 * 2 + widen16_offset(lane);
+    char* orow = a.C + (size_t)mf * a.ldc_bytes + (size_t)(ncol0 + fq) * 2;
+    // rotary rows of token group mt + 1 are fetched while group mt is worked on
+    u32x2_t cq[2][4], sq[2][4];
+    auto fetch = [&](int mt) {
+        const int pos = (mf + mt * 16) % a.L;
+        const char* crow = a.rope_cos + (size_t)pos * 256 + fq * 2;
+        const char* srow = a.rope_sin + (size_t)pos * 256 + fq * 2;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            cq[mt & 1][nt] = *(const u32x2_t*)(crow + nt * 32);
+            sq[mt & 1][nt] = *(const u32x2_t*)(srow + nt * 32);
+        }
+    };
+    fetch(0);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        if (mt + 1 < 8) fetch(mt + 1);
+        unsigned pk[8][2];
+        float t = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            pk[nt][0] = pack_bf16x2(acc[nt][mt][0], acc[nt][mt][1]);
+            pk[nt][1] = pack_bf16x2(acc[nt][mt][2], acc[nt][mt][3]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bf16x2_t v = __builtin_bit_cast(bf16x2_t, pk[nt][h]);
+                t = __builtin_amdgcn_fdot2_f32_bf16(v, v, t, false);
+            }
+        }
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        const float inv = __builtin_amdgcn_rsqf(t * (1.0f / 128.0f) + a.eps);
+        u32x2_t o1[4], o2[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const u32x2_t cv = cq[mt & 1][nt], sv = sq[mt & 1][nt];
+            const float c[4] = {bf16_lo(cv[0]), bf16_hi(cv[0]), bf16_lo(cv[1]), bf16_hi(cv[1])};
+            const float sn[4] = {bf16_lo(sv[0]), bf16_hi(sv[0]), bf16_lo(sv[1]), bf16_hi(sv[1])};
+            float n1[4], n2[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                n1[2 * h] = bf16_lo(pk[nt][h]) * inv; n1[2 * h + 1] = bf16_hi(pk[nt][h]) * inv;
+                n2[2 * h] = bf16_lo(pk[nt + 4][h]) * inv; n2[2 * h + 1] = bf16_hi(pk[nt + 4][h]) * inv;
+            }
+            round_bf16_pair(n1[0], n1[1]); round_bf16_pair(n1[2], n1[3]);
+            round_bf16_pair(n2[0], n2[1]); round_bf16_pair(n2[2], n2[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { n1[r] *= w1[nt][r]; n2[r] *= w2[nt][r]; }
+            round_bf16_pair(n1[0], n1[1]); round_bf16_pair(n1[2], n1[3]);
+            round_bf16_pair(n2[0], n2[1]); round_bf16_pair(n2[2], n2[3]);
+            float pa[4], pb[4], pc[4], pd[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pa[r] = n1[r] * c[r]; pb[r] = n2[r] * sn[r]; pc[r] = n2[r] * c[r]; pd[r] = n1[r] * sn[r]; }
+            round_bf16_pair(pa[0], pa[1]); round_bf16_pair(pa[2], pa[3]);
+            round_bf16_pair(pb[0], pb[1]); round_bf16_pair(pb[2], pb[3]);
+            round_bf16_pair(pc[0], pc[1]); round_bf16_pair(pc[2], pc[3]);
+            round_bf16_pair(pd[0], pd[1]); round_bf16_pair(pd[2], pd[3]);
+            // first half: x1 cos - x2 sin; second half: x2 cos + x1 sin
+            o1[nt] = (u32x2_t){pack_bf16x2(pa[0] - pb[0], pa[1] - pb[1]), pack_bf16x2(pa[2] - pb[2], pa[3] - pb[3])};
+            o2[nt] = (u32x2_t){pack_bf16x2(pc[0] + pd[0], pc[1] + pd[1]), pack_bf16x2(pc[2] + pd[2], pc[3] + pd[3])};
+        }
+        if (wide) {                           // 16-byte pieces: block pairs (0,1) and (2,3) of each half
+            *(u32x4_t*)(ow + mt * rs) = widen16(o1[0], o1[1]);
+            *(u32x4_t*)(ow + mt * rs + 64) = widen16(o1[2], o1[3]);
+            *(u32x4_t*)(ow + mt * rs + 128) = widen16(o2[0], o2[1]);
+            *(u32x4_t*)(ow + mt * rs + 192) = widen16(o2[2], o2[3]);
+        } else if (full || mf + mt * 16 < a.M) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                *(u32x2_t*)(orow + mt * rs + nt * 32) = o1[nt];
+                *(u32x2_t*)(orow + mt * rs + nt * 32 + 128) = o2[nt];
+            }
+        }
+    }
+}
+
 template <int EPI, int MT>
 __global__ __launch_bounds__(256, 1) void gemm256w4_bf16_kernel(GemmArgs a) {
     using T = tile256w4::Tile<MT>;
@@ -885,7 +990,9 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_bf16_kernel(GemmArgs a) {
     const int G = gridDim.x;
     const int slot = xcd_remap(blockIdx.x, G);
     const int nk = a.K / T::BK;
-    constexpr int GROUP_M = 4;
+    // the fused-QKV launch uses 3 row tiles per group: with 4 a workgroup's tiles (slot + k * 256) all fall in one column band,
+    // so a quarter of the CUs would own nothing but the cheap V tiles
+    constexpr int GROUP_M = EPI == EPI_QKROPE ? 3 : 4;
     const int per_group = GROUP_M * a.tiles_n;
     auto coords = [&](int L, int& m0, int& n0) {
         const int g = L / per_group, gm0 = g * GROUP_M;
@@ -1013,8 +1120,13 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_bf16_kernel(GemmArgs a) {
         }
         const bool full = cm0 + T::BM <= a.M && cn0 + T::BN <= a.N;
         const int mrow0 = cm0 + wm * (T::BM / 2), ncol0 = cn0 + wn * 128;
-        epilogue_tile<EPI, MT>(a, *(const f32x4_t(*)[4][MT])&acc[0], mrow0, ncol0, lane, full);
-        epilogue_tile<EPI, MT>(a, *(const f32x4_t(*)[4][MT])&acc[4], mrow0, ncol0 + 64, lane, full);
+        if constexpr (EPI == EPI_QKROPE) {
+            static_assert(EPI != EPI_QKROPE || MT == 8, "the fused q/k epilogue is written for 256-token tiles");
+            epilogue256w4_qkrope(a, acc, mrow0, ncol0, lane, full);
+        } else {
+            epilogue_tile<EPI, MT>(a, *(const f32x4_t(*)[4][MT])&acc[0], mrow0, ncol0, lane, full);
+            epilogue_tile<EPI, MT>(a, *(const f32x4_t(*)[4][MT])&acc[4], mrow0, ncol0 + 64, lane, full);
+        }
         stores_in_flight = full ? (a.wide && EPI != EPI_F32 ? ST_WIDE : ST_NARROW) : 0;
     }
 }
@@ -1198,6 +1310,32 @@ extern "C" int coda_qkv_proj_rope(const void* X, long long ldx, const void* W, l
     return launch256p<EPI_QKROPE>(a, (hipStream_t)stream);
 }
 
+
+// QKV projection + q/k-norm + rotary on the four-wave engine; W in its natural row order (q | k | v heads).
+extern "C" int coda_qkv_proj_rope_w4(const void* X, long long ldx, const void* W, long long ldw, void* qkv, long long ld,
+                                     const void* q_weight, const void* k_weight, const void* cos, const void* sin, int T, int L,
+                                     int n_q, int n_kv, int K, float eps, void* stream) {
+    const int N = (n_q + 2 * n_kv) * 128;
+    if (T < 256 || L <= 0 || T % L || n_q <= 0 || n_kv <= 0 || K <= 0 || K % 64) return CODA_ERR_SHAPE;
+    if ((n_q * 128) % 256 || (n_kv * 128) % 256 || ld < N) return CODA_ERR_SHAPE;
+    if (!X || !W || !qkv || !q_weight || !k_weight || !cos || !sin) return CODA_ERR_ARG;
+    if (((uintptr_t)X | (uintptr_t)W | (uintptr_t)qkv | (uintptr_t)q_weight | (uintptr_t)k_weight | (uintptr_t)cos | (uintptr_t)sin) & 15 ||
+        (ldx * 2) % 16 || (ldw * 2) % 16 || (ld * 2) % 16)
+        return CODA_ERR_ALIGN;
+    if ((size_t)T * ldx * 2 >= 0xffffffffull || (size_t)N * ldw * 2 >= 0xffffffffull) return CODA_ERR_SHAPE;
+    GemmArgs a{};
+    a.ksplit = 1;
+    a.X = (const char*)X; a.ldx_bytes = ldx * 2; a.x_rows = nullptr;
+    a.W = (const char*)W; a.ldw_bytes = ldw * 2;
+    a.C = (char*)qkv; a.ldc_bytes = ld * 2;
+    a.R = nullptr; a.ldr_bytes = 0;
+    a.M = T; a.N = N; a.K = K;
+    a.wide = 1;                               // alignment checked above
+    a.qn_w = (const char*)q_weight; a.kn_w = (const char*)k_weight;
+    a.rope_cos = (const char*)cos; a.rope_sin = (const char*)sin;
+    a.L = L; a.q_feat = n_q * 128; a.qk_feat = (n_q + n_kv) * 128; a.eps = eps;
+    return launch256w4<EPI_QKROPE, 8>(a, (hipStream_t)stream);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Split-K for small M (the B = 1 serving shape): at M = 384 a projection has 48-96 tiles of 128x128, so 48-96 of the 256

@@ -113,11 +113,9 @@ class HipEngine:
                 wo=w(p + "self_attn.o_proj.weight"),
                 wgu=interleave_gate_up(w(p + "mlp.gate_proj.weight"), w(p + "mlp.up_proj.weight")),
                 wd=w(p + "mlp.down_proj.weight")))
-        # fused QKV + q/k-norm + RoPE needs whole 256-feature tiles inside the q and the k block
+        # fused QKV + q/k-norm + RoPE (four-wave engine: a wave's 128 features are one head, weights in their natural row
+        # order - no packed copy) needs whole 256-feature tiles inside the q and the k block
         self.fuse_qk = self.n_q % 2 == 0 and self.n_kv % 2 == 0
-        if self.fuse_qk:
-            for lw in self.lw:
-                lw["wqkv_rope"] = permute_qk_rows(lw["wqkv"], self.n_q, self.n_kv, self.d)
         self._shape = None
         self._rope = {}
         self.timer = None          # optional KernelTimer (bench.py)
@@ -167,14 +165,18 @@ class HipEngine:
             raise _lib.CodaHipError(f"{what} must be {dtype}, got {t.dtype}")
         return t
 
-    def _gemm(self, name, X, W, C, epi, R=None, rows=None, M=None):
+    def _gemm(self, name, X, W, C, epi, R=None, rows=None, M=None, split_like=None):
+        """``split_like``: row count whose split-K factor this call must use (the compact tail runs on few rows but has to
+        sum K in the same order as the full forward would, so that its rows stay bit-identical to it)."""
         M = X.shape[0] if M is None else M
         N, K = W.shape
         ldc = C.stride(0)
         t = self.timer
         if t is not None:
             t.begin(name, 2.0 * M * N * K)
-        ks = splitk_factor(M, N, K) if (rows is None and epi != _lib.EPI_F32 and N % 32 == 0) else 1
+        ks = splitk_factor(M if split_like is None else split_like, N, K) if (rows is None and epi != _lib.EPI_F32 and N % 32 == 0) else 1
+        if ks > 1 and ks * M * N * 4 > SPLITK_WS_BYTES:
+            ks = 1
         if ks > 1:
             if getattr(self, "_splitk_ws", None) is None:
                 self._splitk_ws = torch.empty(SPLITK_WS_BYTES, device=self.device, dtype=torch.uint8)
@@ -236,7 +238,7 @@ class HipEngine:
                 t = self.timer
                 if t is not None:
                     t.begin("qkv", 2.0 * T * self.qkv_dim * self.H)
-                _lib.call("coda_qkv_proj_rope", _ptr(self.a), self.H, _ptr(lw["wqkv_rope"]), self.H, _ptr(self.qkv), self.qkv_dim,
+                _lib.call("coda_qkv_proj_rope_w4", _ptr(self.a), self.H, _ptr(lw["wqkv"]), self.H, _ptr(self.qkv), self.qkv_dim,
                           _ptr(lw["qn"]), _ptr(lw["kn"]), _ptr(cos), _ptr(sin), T, L, self.n_q, self.n_kv, self.H, self.eps, s)
                 if t is not None:
                     t.end("qkv")
@@ -261,10 +263,11 @@ class HipEngine:
         R, s, D = rows.numel(), self._stream(), self.n_q * self.d
         _lib.call("coda_gather_rows", _ptr(self.ao), D, _ptr(rows), None, R, _ptr(self.ao_c), D, D, s)
         _lib.call("coda_gather_rows", _ptr(self.h), self.H, _ptr(rows), None, R, _ptr(self.h_c), self.H, self.H, s)
-        self._gemm("o_proj_tail", self.ao_c, lw["wo"], self.h_c, _lib.EPI_RESIDUAL, R=self.h_c)
+        T = B * L                                # K is summed in the ranges the full forward uses at T rows: bit-identical rows
+        self._gemm("o_proj_tail", self.ao_c, lw["wo"], self.h_c, _lib.EPI_RESIDUAL, R=self.h_c, split_like=T)
         _lib.call("coda_rmsnorm", _ptr(self.h_c), self.H, _ptr(lw["n_post"]), _ptr(self.a_c), self.H, R, self.H, self.eps, s)
-        self._gemm("gate_up_tail", self.a_c, lw["wgu"], self.mlp_c, _lib.EPI_SWIGLU)
-        self._gemm("down_tail", self.mlp_c, lw["wd"], self.h_c, _lib.EPI_RESIDUAL, R=self.h_c)
+        self._gemm("gate_up_tail", self.a_c, lw["wgu"], self.mlp_c, _lib.EPI_SWIGLU, split_like=T)
+        self._gemm("down_tail", self.mlp_c, lw["wd"], self.h_c, _lib.EPI_RESIDUAL, R=self.h_c, split_like=T)
         _lib.call("coda_rmsnorm", _ptr(self.h_c), self.H, _ptr(self.final_norm), _ptr(self.hn_c), self.H, R, self.H, self.eps, s)
         _lib.call("coda_scatter_rows", _ptr(self.hn_c), self.H, _ptr(rows), R, _ptr(self.hn), self.H, B * L, self.H, s)
         return self.hn

@@ -98,6 +98,12 @@ int coda_qkv_proj_rope(const void* X, long long ldx, const void* W, long long ld
                        const void* q_weight, const void* k_weight, const void* cos, const void* sin, int T, int L, int n_q,
                        int n_kv, int K, float eps, void* stream);
 
+/* The same fused launch on the four-wave engine (one wave per SIMD, a wave's 128 features = one head): W in its NATURAL
+ * row order (q | k | v heads, no permutation), same results.  Requires T >= 256, n_q and n_kv even. */
+int coda_qkv_proj_rope_w4(const void* X, long long ldx, const void* W, long long ldw, void* qkv, long long ld,
+                          const void* q_weight, const void* k_weight, const void* cos, const void* sin, int T, int L, int n_q,
+                          int n_kv, int K, float eps, void* stream);
+
 /* Candidate-row compaction and the projection over a device-side row count: the two halves of
  * `logits[mask_index]` (generation_utils.py:462) when logits must be materialised (top-p, top-k).
  * coda_gather_rows: dst[i] = src[rows[i]] for i < min(count[0], max_rows) (count NULL: all), H bf16 per row.

@@ -67,12 +67,42 @@ def test_c2_deterministic_and_row_independent(full):
     kw = dict(max_new_tokens=G, steps=STEPS, alg="entropy", temperature=0.0, block_length=BL, mask_token_id=cfg.mask_token_id)
     again = m.diffusion_generate(ids.to(DEV), **kw).cpu()
     assert torch.equal(again, seq)
-    # rows do not interact: a 4-row shard of the batch reproduces its rows.  Smaller launches take other
-    # tile engines and lm-head split geometries, i.e. other fp32 summation orders: near-ties may flip, so this is a rate
-    sub = m.diffusion_generate(ids[8:12].to(DEV), **kw).cpu()
-    rate = (sub == seq[8:12])[:, P:].float().mean().item()
-    print(f"row independence: 4-row shard vs the same rows of the 32-row run: {rate:.4f} of generated tokens equal")
-    assert rate > 0.9
+    # Rows do not interact.  A 4-row shard takes other code paths than the 32-row batch (T = 1536 tokens:
+    # unfused QKV + standalone norm/rotary kernel, split-K in the compact tail, other lm-head split geometry), i.e. other fp32
+    # summation orders, so its bf16 values differ from the batch's by an ulp here and there; free running, the first
+    # near-tie that flips then changes every later step (F5), which says nothing about coupling.  So the check is ONE
+    # denoise step from the same state: hidden states within a few bf16 ulps, confidences close, tokens equal except on
+    # near-ties.
+    eng = m.hip_engine()
+    rows = slice(8, 12)
+    step = 40
+    blk = step // (STEPS // (G // BL))
+    lo, hi = P + blk * BL, P + (blk + 1) * BL
+    out = {}
+    for name, xs in (("batch", hist[step - 1].to(DEV)), ("shard", hist[step - 1][rows].to(DEV))):
+        eng.set_mask_id(cfg.mask_token_id)
+        hn = eng.forward_hidden(xs, need=(lo - 1, hi - 1)).view(xs.shape[0], L, -1)[:, lo - 1:hi - 1].float().clone()
+        eng.build_candidates(xs, lo, hi)
+        eng.lmhead_confidence(xs.shape[0] * BL, 2, 0.0, None, 0, False)
+        torch.cuda.synchronize()
+        n = int(eng.count.item())
+        dst = eng.dst_pos[:n].long()
+        out[name] = (hn, dst.cpu(), eng.conf[dst].cpu().clone(), eng.x0[dst].cpu().clone())
+    hb, db, cb, xb = out["batch"]
+    hs, ds, cs, xs_ = out["shard"]
+    hb = hb[rows]
+    sel = (db // L >= 8) & (db // L < 12)
+    assert torch.equal(db[sel] - 8 * L, ds)                               # same candidate positions
+    dh = (hb - hs).abs()
+    tok_same = (xb[sel] == xs_).float().mean().item()
+    dc = (cb[sel] - cs).abs()
+    print(f"row independence, one step from the same state (4-row shard vs the same rows of the 32-row batch): hidden max |diff| "
+          f"{dh.max():.3g} mean {dh.mean():.3g} (mean |h| {hb.abs().mean():.3g}); {ds.numel()} candidates, tokens equal {tok_same:.3f}, "
+          f"max |conf diff| {dc.max():.3g}")
+    # measured: mean |diff| 1.6 % of mean |h| (the same size as the HIP-vs-CPU-oracle deviation of this random-init 28-layer
+    # model: one-ulp differences grow through the layers), 61 of 68 tokens equal, the others near-ties
+    assert dh.mean().item() < 0.04 * hb.abs().mean().item() and dh.max().item() < 0.5
+    assert tok_same >= 0.8 and dc.median().item() < 0.05
 
 
 def test_c2_last_layer_compact_tail_equals_full_forward(full):

@@ -276,8 +276,9 @@ def test_qknorm_rope():
     assert (out.float() - ref.float()).abs().max() < 0.05
 
 
-@pytest.mark.parametrize("B,L,n_q,n_kv,K", [(2, 200, 4, 2, 256), (3, 128, 2, 2, 128), (1, 300, 16, 8, 2048)])
-def test_fused_qkv_rope_equals_two_call_path(B, L, n_q, n_kv, K):
+@pytest.mark.parametrize("entry", ["coda_qkv_proj_rope", "coda_qkv_proj_rope_w4"])
+@pytest.mark.parametrize("B,L,n_q,n_kv,K", [(2, 200, 4, 2, 256), (3, 128, 2, 2, 128), (1, 300, 16, 8, 2048), (5, 333, 4, 2, 512)])
+def test_fused_qkv_rope_equals_two_call_path(B, L, n_q, n_kv, K, entry):
     """coda_qkv_proj_rope (fused epilogue, permuted weight rows) vs coda_gemm_bf16 + coda_qknorm_rope."""
     from coda_amd.engine import permute_qk_rows
     g = torch.Generator().manual_seed(40)
@@ -291,8 +292,11 @@ def test_fused_qkv_rope_equals_two_call_path(B, L, n_q, n_kv, K):
     ref = gemm(X, W, _lib.EPI_PLAIN)
     _lib.call("coda_qknorm_rope", _p(ref), N, _p(qw), _p(kw), _p(cos), _p(sin), T, L, n_q, n_kv, 1e-6, _s())
     out = torch.full((T, N), float("nan"), device=DEV, dtype=BF)
-    Wp = permute_qk_rows(W, n_q, n_kv)
-    _lib.call("coda_qkv_proj_rope", _p(X), K, _p(Wp), K, _p(out), N, _p(qw), _p(kw), _p(cos), _p(sin), T, L, n_q, n_kv, K, 1e-6, _s())
+    if entry == "coda_qkv_proj_rope":
+        Wp = permute_qk_rows(W, n_q, n_kv)        # the eight-wave engine wants rotary partners in one MFMA lane
+    else:
+        Wp = W                                    # four-wave engine: a wave owns a whole head, natural row order
+    _lib.call(entry, _p(X), K, _p(Wp), K, _p(out), N, _p(qw), _p(kw), _p(cos), _p(sin), T, L, n_q, n_kv, K, 1e-6, _s())
     torch.cuda.synchronize()
     assert torch.equal(out[:, (n_q + n_kv) * d:], ref[:, (n_q + n_kv) * d:])                 # V: plain projection
     same = (out == ref).float().mean().item()
