@@ -55,7 +55,9 @@ __device__ __forceinline__ float coda_hash_uniform(unsigned int seed_lo, unsigne
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     h += seed_hi;
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
-    return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    // 23 bits + 0.5: every value is exact in fp32 and u lies in [2^-24, 1 - 2^-24].  (24 bits + 0.5 needs 25 significant
+    // bits: the top value rounds to 1.0, -log(u) = 0, and the race key of that entry becomes +inf - it wins whatever its logit.)
+    return ((float)(h >> 9) + 0.5f) * (1.0f / 8388608.0f);
 }
 
 // x / t for a loop-invariant divisor, correctly rounded like the IEEE quotient (what `logits / temperature` is in the
@@ -70,8 +72,8 @@ __device__ __forceinline__ float coda_div_by(float x, float t, float rt) {
     return __builtin_isinf(x) ? x : q1;
 }
 
-// Exponential race with coda_hash_uniform noise: key = logit - log(-log(u)), u in [2^-25, 1 - 2^-25], so the noise term
-// lies in [-2.86, 17.33]; an entry more than this far below a known lower bound of the winner's logit cannot win.
+// Exponential race with coda_hash_uniform noise: key = logit - log(-log(u)), u in [2^-24, 1 - 2^-24], so the noise term
+// lies in [-2.82, 16.64]; an entry more than this far below a known lower bound of the winner's logit cannot win.
 #define CODA_RACE_WINDOW 20.5f
 
 // 16-byte asynchronous global -> LDS copy.  The LDS destination is wave-uniform base + lane*16.

@@ -321,8 +321,8 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
         s += e * d;
         if (x == mx) { ++n_max; arg = min(arg, v); }
         else m2 = fmaxf(m2, x);
-        // In-kernel noise is bounded: u in [2^-25, 1 - 2^-25] gives -log q in [-2.86, 17.33], so the row maximum's key is at
-        // least mx - 2.86 and an entry more than 20.2 below the maximum can never win the race: no hash, no logs for it
+        // In-kernel noise is bounded: u in [2^-24, 1 - 2^-24] gives -log q in [-2.82, 16.64], so the row maximum's key is at
+        // least mx - 2.82 and an entry more than 19.5 below the maximum can never win the race: no hash, no logs for it
         // (on peaked rows that is nearly the whole vocabulary, and the race is what a sampled pass costs).
         if (sampled && (a.noise || x >= mx - CODA_RACE_WINDOW)) {
             const float q = a.noise ? a.noise[(size_t)row * V + v] : -__logf(coda_hash_uniform(a.seed_lo, a.seed_hi, rowkey, (unsigned)v));

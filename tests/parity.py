@@ -79,7 +79,7 @@ def hash_uniform_host(seed: int, rowkey: torch.Tensor, v) -> torch.Tensor:
     h = h ^ (h >> 16); h = (h * 0x85EBCA6B) & M; h = h ^ (h >> 13); h = (h * 0xC2B2AE35) & M; h = h ^ (h >> 16)
     h = (h + hi) & M
     h = h ^ (h >> 15); h = (h * 0x2C1B3C6D) & M; h = h ^ (h >> 12); h = (h * 0x297A2D39) & M; h = h ^ (h >> 15)
-    return ((h >> 8).to(torch.float32) + 0.5) * (1.0 / 16777216.0)
+    return ((h >> 9).to(torch.float32) + 0.5) * (1.0 / 8388608.0)
 
 
 def subsample(x_init, hist, trace, rows, steps):

@@ -580,6 +580,66 @@ def test_lmhead_confidence_exact_logits(V, n_rows):
         assert torch.isnan(conf.cpu()[untouched]).all()
 
 
+@pytest.mark.parametrize("V,n_rows", [(1536 + 4, 37), (5000, 300), (1024, 5000)])
+def test_lmhead_confidence_exact_logits_many_rows(V, n_rows):
+    """The same known-answer check with a launch bound of 8192 candidate rows out of a 6000-row hidden buffer (every masked
+    position of a long generation goes through the lm-head at once): row counts below one 128-row block and far above it."""
+    g = torch.Generator().manual_seed(25)
+    H, T = 128, 6000
+    hidden = torch.randint(-2, 3, (T, H), generator=g).to(BF)
+    W = torch.randint(-1, 2, (V, H), generator=g).to(BF)
+    src = torch.randint(0, T, (n_rows,), generator=g).to(torch.int32)
+    dst = torch.randperm(T, generator=g)[:n_rows].to(torch.int32)
+    cnt = torch.tensor([n_rows], dtype=torch.int32)
+    rows = (hidden.float()[src.long()] @ W.float().t()).to(BF).float() * 0.25
+    hid_s = (hidden.float() * 0.25).to(BF)
+    for alg_id, kw in ((0, {}), (1, dict(margin=True)), (2, dict(neg_entropy=True))):
+        c_ref, x_ref = ref_cpu.sample_tokens(rows, 0.0, **kw)
+        conf, x0 = _lmhead(hid_s.to(DEV), W.to(DEV), src.to(DEV), dst.to(DEV), cnt.to(DEV), 8192, alg_id, T_total=T)
+        assert torch.equal(x0.cpu()[dst.long()], x_ref), alg_id
+        assert (conf.cpu()[dst.long()] - c_ref).abs().max() < 1e-4, alg_id
+        untouched = torch.ones(T, dtype=torch.bool)
+        untouched[dst.long()] = False
+        assert torch.isnan(conf.cpu()[untouched]).all()
+
+
+@pytest.mark.parametrize("temperature", [0.0, 0.7])
+def test_lmhead_confidence_independent_of_the_launch_bound(temperature):
+    """Full vocabulary, random-normal data, 700 candidate rows: the work split is derived from the row count read on the
+    device, not from the launch bound, so any bound >= the count gives the same bits - greedy and with in-kernel noise."""
+    g = torch.Generator().manual_seed(26)
+    H, V, n_rows = 256, 151936, 700
+    hidden = torch.randn(n_rows, H, generator=g).to(BF).to(DEV)
+    W = (torch.randn(V, H, generator=g) * 0.25).to(BF).to(DEV)
+    src = torch.randperm(n_rows, generator=g).to(torch.int32).to(DEV)
+    dst = torch.arange(n_rows, dtype=torch.int32).to(DEV)
+    cnt = torch.tensor([n_rows], dtype=torch.int32).to(DEV)
+    for alg_id in (0, 1, 2):
+        c4, x4 = _lmhead(hidden, W, src, dst, cnt, 4096, alg_id, temperature=temperature, T_total=n_rows, seed=77)
+        c1, x1 = _lmhead(hidden, W, src, dst, cnt, 1024, alg_id, temperature=temperature, T_total=n_rows, seed=77)
+        assert torch.equal(x4, x1) and torch.equal(c4, c1), alg_id
+
+
+def test_in_kernel_noise_top_hash_value_does_not_win():
+    """Regression: (seed 77, row key 565, token 148599) hashes to the largest value.  With 24 hash bits + 0.5 that became
+    u = 1.0 in fp32, -log(u) = 0 and a race key of +inf: the token won whatever its logit.  u now stays below 1, the key is
+    finite, and on a flat row the winner is whoever the host restatement of the hash says."""
+    seed, row, V, T = 77, 565, 151936, 0.7
+    u = hash_uniform_host(seed, row, torch.arange(V))
+    assert int(u.argmax()) == 148599 and float(u.max()) == 1.0 - 2.0 ** -24
+    key = -torch.log(-torch.log(u))                      # flat row: the logits add nothing
+    assert torch.isfinite(key).all()
+    logits = torch.zeros(row + 1, V, dtype=BF)
+    logits[row, 148599] = -8.0                           # and this entry in particular cannot win from 8 below the rest
+    key[148599] += -8.0 / T
+    conf = torch.full((row + 1,), float("nan"), device=DEV)
+    x0 = torch.full((row + 1,), -1, device=DEV, dtype=torch.int64)
+    ld = logits.to(DEV)
+    _lib.call("coda_confidence_from_logits", _p(ld), V, 1, row + 1, V, None, None, 0, T, 0.0, 0, None, seed, 0, _p(conf), _p(x0), _s())
+    torch.cuda.synchronize()
+    assert int(x0[row]) == int(key.argmax()) != 148599
+
+
 def test_lmhead_confidence_sampled_with_injected_noise():
     g = torch.Generator().manual_seed(16)
     H, T, V, n_rows = 128, 200, 2048, 70
@@ -598,10 +658,11 @@ def test_lmhead_confidence_sampled_with_injected_noise():
     c_ref, x_ref = ref_cpu.sample_tokens(logits.float(), temp, noise=N())
     noise = torch.ones(128, V)
     noise[:n_rows] = q
-    conf, x0 = _lmhead(hidden.to(DEV), W.to(DEV), src.to(DEV), dst.to(DEV), cnt.to(DEV), 128, 0, temperature=temp,
-                       noise=noise.to(DEV), T_total=T)
-    assert torch.equal(x0.cpu()[dst.long()], x_ref)
-    assert (conf.cpu()[dst.long()] - c_ref).abs().max() < 1e-4
+    for cap in (128, 4096):                  # a block's worth of candidates / a long generation's launch bound
+        conf, x0 = _lmhead(hidden.to(DEV), W.to(DEV), src.to(DEV), dst.to(DEV), cnt.to(DEV), cap, 0, temperature=temp,
+                           noise=noise.to(DEV), T_total=T)
+        assert torch.equal(x0.cpu()[dst.long()], x_ref), cap
+        assert (conf.cpu()[dst.long()] - c_ref).abs().max() < 1e-4, cap
 
 
 def test_lmhead_confidence_full_vocab_random():

@@ -1,4 +1,5 @@
 """CPU-side checks: C-ABI library exports, config/generation-config contract, schedules, DP sharding."""
+import math
 import os
 import subprocess
 import sys
@@ -286,3 +287,21 @@ def test_three_operation_division_is_correctly_rounded():
             q1 = rn32(q0 + r * rt)
             bad += q1 != rn32(xf / t32)
         assert bad == 0, (t, bad)
+
+
+def test_hash_uniform_stays_strictly_inside_the_unit_interval():
+    """coda_hash_uniform's mapping of the 32-bit hash to fp32 (restated in tests/parity.py): every value exact in fp32 and
+    strictly inside (0, 1).  With 24 bits + 0.5 the top value rounded to 1.0, -log(u) became 0 and that entry's race key
+    +inf: it won the exponential race whatever its logit (found by the cross-check of the two lm-head kernels)."""
+    import numpy as np
+    top = np.float32(np.float32(0xFFFFFFFF >> 9) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
+    bot = np.float32(np.float32(0) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
+    assert 0.0 < float(bot) == 2.0 ** -24 and float(top) == 1.0 - 2.0 ** -24 < 1.0
+    noise = [-math.log(-math.log(float(u))) for u in (bot, top)]
+    assert -2.82 < noise[0] < noise[1] < 16.64          # the bounds CODA_RACE_WINDOW (20.5) is built on
+    old_top = np.float32(np.float32(0xFFFFFFFF >> 8) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    assert float(old_top) == 1.0                         # what the previous mapping did
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from parity import hash_uniform_host
+    u = hash_uniform_host(0x1234567890, torch.arange(64)[:, None], torch.arange(4096)[None, :])
+    assert float(u.min()) >= 2.0 ** -24 and float(u.max()) <= 1.0 - 2.0 ** -24
