@@ -830,3 +830,107 @@ def test_in_kernel_token_noise_race_matches_host_hash(scale):
     c2, z2 = _lmhead(hidden.to(DEV), W.to(DEV), src.to(DEV), src.to(DEV), torch.tensor([N], dtype=torch.int32).to(DEV), 128, 0,
                      temperature=T, T_total=N, seed=seed)
     assert torch.equal(z2.cpu()[clear], want[clear])
+
+
+def _chi2(counts, probs, n):
+    exp = probs.double() * n
+    keep = exp > 5                                    # pool the far tail into one cell
+    c = torch.cat([counts.double()[keep], counts.double()[~keep].sum()[None]])
+    e = torch.cat([exp[keep], exp[~keep].sum()[None]])
+    if e[-1] == 0:
+        c, e = c[:-1], e[:-1]
+    return float(((c - e) ** 2 / e).sum()), c.numel() - 1
+
+
+@pytest.mark.parametrize("top_p", [0.0, 0.9])
+def test_in_kernel_sampling_follows_the_softmax(top_p):
+    """The production path for temperature > 0 draws its noise in the kernel (counter hash -> exponential race).  The
+    other noise tests compare it with a host restatement of the SAME hash, which a statistically poor hash would pass; this
+    one asks the question that matters: 131 072 draws (8192 rows x 16 step seeds) from one 512-way distribution must fit
+    softmax(l / T) - or its top-p nucleus, renormalised - by chi-square (6 sigma), through the unfused and the fused kernel,
+    and the draws of neighbouring rows and of consecutive seeds must be independent (chi-square on coarse pairs)."""
+    g = torch.Generator().manual_seed(91)
+    V, H, N, T, n_seeds = 512, 64, 8192, 0.7, 16
+    hvec = torch.randint(-2, 3, (H,), generator=g).float()
+    W = (torch.randint(-2, 3, (V, H), generator=g).float() / 4).to(BF)                 # exact products
+    row = (W.float() @ hvec).to(BF)
+    lt = (row.float() / T).to(BF).float()
+    p = torch.softmax(lt, -1)
+    if top_p > 0:
+        srt, idx = torch.sort(p, descending=True)
+        cum = torch.cumsum(srt, -1)
+        keep_sorted = (cum - srt) < top_p                                            # the reference keeps the first token past top_p
+        mask = torch.zeros(V, dtype=torch.bool)
+        mask[idx[keep_sorted]] = True
+        p = torch.where(mask, p, torch.zeros_like(p))
+        p = p / p.sum()
+    logits = row[None, :].expand(N, V).contiguous().to(DEV)
+    hidden = hvec.to(BF)[None, :].expand(N, H).contiguous().to(DEV)
+    src = torch.arange(N, dtype=torch.int32, device=DEV)
+    cnt = torch.tensor([N], dtype=torch.int32, device=DEV)
+    draws = {"unfused": [], "fused": []}
+    for k in range(n_seeds):
+        seed = 0x5EED_0000_0000 + 7919 * k
+        conf = torch.empty(N, device=DEV)
+        x0 = torch.empty(N, device=DEV, dtype=torch.int64)
+        _lib.call("coda_confidence_from_logits", _p(logits), V, 1, N, V, None, None, 0, T, top_p, 0, None, seed, 0, _p(conf), _p(x0), _s())
+        torch.cuda.synchronize()
+        draws["unfused"].append(x0.cpu())
+        if top_p == 0:
+            _, z = _lmhead(hidden, W.to(DEV), src, src, cnt, N, 0, temperature=T, T_total=N, seed=seed)
+            draws["fused"].append(z.cpu())
+    for name, d in draws.items():
+        if not d:
+            continue
+        x = torch.stack(d)                                                            # [seeds, rows]
+        n = x.numel()
+        chi, dof = _chi2(torch.bincount(x.flatten(), minlength=V), p, n)
+        assert chi < dof + 6 * (2 * dof) ** 0.5, (name, chi, dof)
+        assert (p[x.flatten()] > 0).all(), name                                        # nothing outside the nucleus
+        # independence: rank of the token in the sorted distribution, binned into 6 classes of about equal mass
+        order = torch.argsort(p, descending=True)
+        cls_of = torch.empty(V, dtype=torch.long)
+        cls_of[order] = torch.clamp((torch.cumsum(p[order], -1) * 6).long(), max=5)
+        c = cls_of[x]
+        pc = torch.bincount(cls_of, weights=p.double(), minlength=6).float()
+        for a, b, what in ((c[:, :-1], c[:, 1:], "neighbouring rows"), (c[:-1], c[1:], "consecutive seeds")):
+            joint = torch.bincount((a * 6 + b).flatten(), minlength=36)
+            chi, dof = _chi2(joint, (pc[:, None] * pc[None, :]).flatten(), a.numel())
+            assert chi < dof + 6 * (2 * dof) ** 0.5, (name, what, chi, dof)
+
+
+def test_in_kernel_selection_and_origin_noise_distributions():
+    """Same question for the other two in-kernel noise streams.  alg_temp > 0: one position is revealed per row (k = 1), and
+    over 16 384 rows x 8 seeds the revealed position must follow softmax(confidence / alg_temp) (generation_utils.py:523-527:
+    multinomial without replacement == this race).  origin: each candidate is taken with probability p_transfer."""
+    B, L, mask_id, alg_temp = 16384, 8, 7, 0.5
+    conf_row = torch.tensor([-0.1, -0.9, -0.3, -2.0, -0.5, -1.4, -0.2, -0.7])
+    p = torch.softmax(conf_row / alg_temp, -1)
+    x = torch.full((B, L), mask_id, dtype=torch.int64)
+    x0 = (100 + torch.arange(L))[None, :].expand(B, L).contiguous()
+    conf = conf_row[None, :].expand(B, L).contiguous().to(DEV)
+    src, dst, cnt = _candidates(x, 0, L, mask_id)
+    picks = []
+    for k in range(8):
+        xd = x.to(DEV)
+        _lib.call("coda_select_unmask", _p(xd), _p(conf), _p(x0.to(DEV)), _p(cnt), B, L, 0, L, mask_id, 0.13, 0, alg_temp, None,
+                  0xABCD_0000 + 104729 * k, None, _s())
+        torch.cuda.synchronize()
+        changed = xd.cpu() != mask_id
+        assert (changed.sum(1) == 1).all()
+        picks.append(changed.float().argmax(1))
+    picks = torch.stack(picks)
+    chi, dof = _chi2(torch.bincount(picks.flatten(), minlength=L), p, picks.numel())
+    assert chi < dof + 6 * (2 * dof) ** 0.5, (chi, dof)
+    for a, b, what in ((picks[:, :-1], picks[:, 1:], "neighbouring rows"), (picks[:-1], picks[1:], "consecutive seeds")):
+        chi, dof = _chi2(torch.bincount((a * L + b).flatten(), minlength=L * L), (p[:, None] * p[None, :]).flatten(), a.numel())
+        assert chi < dof + 6 * (2 * dof) ** 0.5, (what, chi, dof)
+    n = B * L
+    for p_t in (0.1, 0.5):
+        xd = x.to(DEV)
+        _lib.call("coda_origin_transfer", _p(xd), _p(x0.to(DEV)), _p(dst), _p(cnt), n, None, 0x77AA_55 + int(p_t * 100), p_t, _s())
+        torch.cuda.synchronize()
+        taken = (xd.cpu() != mask_id)
+        assert abs(taken.float().mean().item() - p_t) < 6 * (p_t * (1 - p_t) / n) ** 0.5, p_t
+        per_pos = taken.float().mean(0)                                                # no position favoured
+        assert (per_pos - p_t).abs().max() < 6 * (p_t * (1 - p_t) / B) ** 0.5, p_t
