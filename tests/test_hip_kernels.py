@@ -842,8 +842,8 @@ def _chi2(counts, probs, n):
     return float(((c - e) ** 2 / e).sum()), c.numel() - 1
 
 
-@pytest.mark.parametrize("top_p", [0.0, 0.9])
-def test_in_kernel_sampling_follows_the_softmax(top_p):
+@pytest.mark.parametrize("top_p,top_k", [(0.0, 0), (0.9, 0), (0.0, 20)])
+def test_in_kernel_sampling_follows_the_softmax(top_p, top_k):
     """The production path for temperature > 0 draws its noise in the kernel (counter hash -> exponential race).  The
     other noise tests compare it with a host restatement of the SAME hash, which a statistically poor hash would pass; this
     one asks the question that matters: 131 072 draws (8192 rows x 16 step seeds) from one 512-way distribution must fit
@@ -864,6 +864,10 @@ def test_in_kernel_sampling_follows_the_softmax(top_p):
         mask[idx[keep_sorted]] = True
         p = torch.where(mask, p, torch.zeros_like(p))
         p = p / p.sum()
+    if top_k > 0:                                                                    # ties at the k-th value stay (logits < kth removed)
+        kth = torch.topk(lt, top_k).values[-1]
+        p = torch.where(lt >= kth, p, torch.zeros_like(p))
+        p = p / p.sum()
     logits = row[None, :].expand(N, V).contiguous().to(DEV)
     hidden = hvec.to(BF)[None, :].expand(N, H).contiguous().to(DEV)
     src = torch.arange(N, dtype=torch.int32, device=DEV)
@@ -873,10 +877,10 @@ def test_in_kernel_sampling_follows_the_softmax(top_p):
         seed = 0x5EED_0000_0000 + 7919 * k
         conf = torch.empty(N, device=DEV)
         x0 = torch.empty(N, device=DEV, dtype=torch.int64)
-        _lib.call("coda_confidence_from_logits", _p(logits), V, 1, N, V, None, None, 0, T, top_p, 0, None, seed, 0, _p(conf), _p(x0), _s())
+        _lib.call("coda_confidence_from_logits", _p(logits), V, 1, N, V, None, None, 0, T, top_p, top_k, None, seed, 0, _p(conf), _p(x0), _s())
         torch.cuda.synchronize()
         draws["unfused"].append(x0.cpu())
-        if top_p == 0:
+        if top_p == 0 and top_k == 0:
             _, z = _lmhead(hidden, W.to(DEV), src, src, cnt, N, 0, temperature=T, T_total=N, seed=seed)
             draws["fused"].append(z.cpu())
     for name, d in draws.items():
