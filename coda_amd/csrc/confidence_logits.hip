@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
     __shared__ int sh_seg[256];
     __shared__ int sh_k;
     __shared__ int sh_cut;
+    __shared__ int sh_single;
 
     const int row = blockIdx.x;
     const int n_rows = a.count ? min(a.count[0], a.N) : a.N;
@@ -153,7 +154,9 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
             }
             __syncthreads();
             const unsigned int hi_mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+            int n_top = 0;                           // first level only: entries equal to the row maximum
             for_each([&](int, float x) {
+                if (shift == 24) n_top += x == mx ? 1 : 0;
                 // Entries whose fixed-point mass is zero (x more than ~28 below the row maximum: e^-28 * 2^40 < 1) cannot
                 // move the threshold: the running mass crosses top_p * total at an entry with non-zero mass, every
                 // zero-mass entry sorts below it, and the tie count at the last level is taken at the threshold key
@@ -168,6 +171,7 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
                 }
             });
             __syncthreads();
+            if (shift == 24) n_top = block_reduce<int>(n_top, red_i, tid, iadd_op);
             {
                 unsigned long long hm = 0ull;
                 int hi = 0;
@@ -186,6 +190,11 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
                     unsigned long long tot = 0ull;
                     for (int bin = 0; bin < 256; ++bin) tot += hist_m[bin];
                     sh_lim = (unsigned long long)((double)a.top_p * (double)tot);
+                    // A single row maximum whose own mass already exceeds top_p * total is the whole nucleus (the second key
+                    // would be kept only if the mass above it were <= the limit): the same fixed-point comparison the
+                    // levels below would end on, known one pass over the row earlier - most rows of a trained model late
+                    // in the denoising, or at the lm-eval scripts' temperature of 0.1.
+                    sh_single = n_top == 1 && mass(mx) > sh_lim;
                 }
                 const unsigned long long lm = sh_lim;
                 unsigned long long run = acc, pick_acc = acc;
@@ -205,7 +214,14 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
             prefix = sh_prefix;
             acc = sh_acc;
             lim = sh_lim;
+            const bool single = sh_single != 0;
             __syncthreads();
+            if (single) {                            // (wave-uniform: read from LDS after the barrier)
+                prefix = key_of(mx);
+                if (tid == 0) { sh_k = 1; sh_tie_mass = mass(mx); }
+                __syncthreads();
+                break;
+            }
         }
         kp = prefix;
         // ties at the threshold: the reference keeps them one by one while the running mass <= top_p

@@ -728,6 +728,41 @@ def test_confidence_from_logits_all_flavours(V, golden):
             assert (conf - c_ref).abs().max() < tol, (kw, alg_id, (conf - c_ref).abs().max())
 
 
+def test_confidence_top_p_single_token_nucleus_shortcut():
+    """top-p with the row maximum alone above top_p: the kernel knows after its first pass (online softmax) and skips the
+    radix select.  Rows on both sides of the boundary, near and far, tied maxima, a banned (-inf) head of the row: tokens and
+    confidences as the oracle's sort + cumsum gives them, greedy and sampled, every alg."""
+    V, top_p = 4096, 0.9
+    rows = []
+    for pm in (0.5, 0.85, 0.8995, 0.9005, 0.95, 0.999):
+        r = torch.full((V,), -30.0)
+        r[1234] = 0.0
+        r[77] = math.log((1 - pm) / pm)
+        rows.append(r)
+    tied = torch.full((V,), -30.0)
+    tied[5] = tied[4000] = 0.0                      # two maxima of 0.5 each: never a single-token nucleus
+    rows.append(tied)
+    banned = torch.full((V,), -30.0)
+    banned[:64] = -math.inf
+    banned[900] = 3.0
+    rows.append(banned)
+    logits = torch.stack(rows)
+    g = torch.Generator().manual_seed(20)
+    q = torch.empty(len(rows), V).exponential_(1, generator=g)
+
+    class Nz:
+        def token_exp(self, step, probs):
+            return q
+    for t in (0.0, 1.0):
+        for alg_id, okw in ((0, {}), (1, dict(margin=True)), (2, dict(neg_entropy=True))):
+            c_ref, x_ref = ref_cpu.sample_tokens(logits, t, top_p, None, noise=Nz(), **okw)
+            conf, x0 = _conf_logits(logits, alg_id, t, top_p, 0, q if t > 0 else None)
+            assert torch.equal(x0, x_ref), (t, alg_id, x0.tolist(), x_ref.tolist())
+            assert (conf - c_ref).abs().max() < 2e-4, (t, alg_id, conf.tolist(), c_ref.tolist())
+    c, _ = _conf_logits(logits, 0, 0.0, top_p, 0, None)
+    assert c[3] == 1.0 and c[4] == 1.0 and c[5] == 1.0 and abs(c[2] - 0.8995) < 1e-3 and abs(c[6] - 0.5) < 1e-4 and c[7] == 1.0
+
+
 def test_confidence_from_logits_bf16_ties():
     """bf16 logits tie massively; the kept sets of top-p / top-k must follow the documented rule
     (ties at the top-p boundary enter in index order, ties at the k-th value are all kept)."""
