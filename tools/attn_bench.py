@@ -11,6 +11,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from coda_amd import _lib  # noqa: E402
 
+if os.environ.get("ALT_LIB"):                 # a diagnostic build of the library (tools/alt/, not tracked)
+    _lib.LIB_PATH = os.path.abspath(os.environ["ALT_LIB"])
+
 _lib.load()
 splits = [0] + [int(v) for v in os.environ.get("QSPLITS", "").split(",") if v]
 KNOB = os.environ.get("KNOB", "qsplit")
