@@ -36,6 +36,7 @@ SIGNATURES = {
     "coda_confidence_from_logits": (_i, [_p, _ll, _i, _i, _i, _p, _p, _i, _f, _f, _i, _p, _ull, _i, _p, _p, _p]),
     "coda_select_unmask": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _ll, _f, _i, _f, _p, _ull, _p, _p]),
     "coda_gather_rows": (_i, [_p, _ll, _p, _p, _i, _p, _ll, _i, _p]),
+    "coda_chunk_counts": (_i, [_p, _i, _i, _p, _p]),
     "coda_scatter_rows": (_i, [_p, _ll, _p, _i, _p, _ll, _i, _i, _p]),
     "coda_gemm_bf16_counted":(_i, [_p, _ll, _p, _p, _ll, _p, _ll, _i, _i, _i, _p]),
     "coda_select_threshold": (_i, [_p, _p, _p, _i, _i, _i, _ll, _i, _f, _p, _p]),

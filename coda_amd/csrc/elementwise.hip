@@ -52,6 +52,22 @@ extern "C" int coda_gather_rows(const void* src, long long ld_src, const int* ro
     return CODA_OK;
 }
 
+// Row counts of the chunks of a counted launch: out[c] = clamp(count[0] - c * chunk, 0, chunk).  A long candidate list is
+// projected and reduced chunk by chunk (bounded logits buffer); every chunk's kernels read their own count here, so the
+// host still never learns the count.
+__global__ void chunk_counts_kernel(const int* __restrict__ count, int chunk, int n_chunks, int* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_chunks) out[c] = max(0, min(chunk, count[0] - c * chunk));
+}
+
+extern "C" int coda_chunk_counts(const int* count, int chunk, int n_chunks, int* out, void* stream) {
+    if (chunk <= 0 || n_chunks <= 0) return CODA_ERR_SHAPE;
+    if (!count || !out) return CODA_ERR_ARG;
+    hipLaunchKernelGGL(chunk_counts_kernel, dim3((n_chunks + 63) / 64), dim3(64), 0, (hipStream_t)stream, count, chunk, n_chunks, out);
+    CODA_CHECK_LAUNCH("chunk_counts");
+    return CODA_OK;
+}
+
 // inverse of the compaction: dst[rows[i]] = src[i] (the final-normed hidden rows of the last layer's compact tail go
 // back to their token rows, where coda_build_candidates' src_rows point)
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const char* __restrict__ src, long long ld_src_b, const int* __restrict__ rows,

@@ -1277,6 +1277,7 @@ extern "C" int coda_gemm_bf16_counted(const void* X, long long ldx, const int* m
     a.tiles_m = (M_max + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
     a.wide = (((uintptr_t)C | (uintptr_t)(ldc * 2)) & 15) == 0;
     const int engine = pick_engine(a, 0);
+    if (engine == 8) return launch256w4<EPI_PLAIN, 8>(a, (hipStream_t)stream);    // (reads m_count like the engines below)
     if (engine == 6) return launch192x256px<EPI_PLAIN>(a, (hipStream_t)stream);
     if (engine == 5) return launch192x256p<EPI_PLAIN>(a, (hipStream_t)stream);
     if (engine == 3) return launch256p<EPI_PLAIN>(a, (hipStream_t)stream);

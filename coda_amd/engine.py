@@ -120,6 +120,8 @@ class HipEngine:
         self._rope = {}
         self.timer = None          # optional KernelTimer (bench.py)
         self.prune_last_layer = True   # forward_hidden(need=...): last layer's per-token tail on the consumed rows only
+        self.materialise_min_rows = 2048   # launch bound from which lmhead_confidence takes the materialised route
+        self.logits_chunk_rows = 8192      # ... and its logits buffer's rows
 
     # ------------------------------------------------------------------ workspaces
     def _ensure(self, B: int, L: int):
@@ -296,9 +298,39 @@ class HipEngine:
     @_on_device
     def lmhead_confidence(self, max_rows: int, alg: int, temperature: float, noise, seed: int, round_conf: bool):
         self._dev(noise, "token noise", torch.float32)
+        if max_rows >= self.materialise_min_rows:
+            return self._lmhead_materialised(max_rows, alg, temperature, noise, seed, round_conf)
         _lib.call("coda_lmhead_confidence", _ptr(self.hn), self.H, _ptr(self.src_rows), _ptr(self.dst_pos), _ptr(self.count),
                   max_rows, _ptr(self.lm_head), self.H, self.V, self.H, alg, float(temperature), _ptr(noise), seed,
                   int(round_conf), _ptr(self.conf), _ptr(self.x0), _ptr(self.lm_ws), self._stream())
+
+    def _lmhead_materialised(self, max_rows: int, alg: int, temperature: float, noise, seed: int, round_conf: bool):
+        """Same result as the fused kernel by the route that measures faster from ~2k candidate rows on (17 % at 4k-65k rows,
+        `tools/lmhead_unfused_bench.py`): the rows are compacted, projected by the four-wave GEMM engine into a bf16
+        logits buffer and reduced by the confidence kernel - chunk by chunk, so the buffer stays at ``logits_chunk_rows``
+        x V (2.5 GB) however long the candidate list is.  The chunks' row counts are derived on the device."""
+        chunk = min(max_rows, self.logits_chunk_rows)
+        n_chunks = (max_rows + chunk - 1) // chunk
+        if getattr(self, "_mat_rows", 0) < chunk:
+            self._mat_hidden = torch.empty(chunk, self.H, device=self.device, dtype=torch.bfloat16)
+            self._mat_logits = torch.empty(chunk, self.V, device=self.device, dtype=torch.bfloat16)
+            self._mat_rows = chunk
+        if getattr(self, "_mat_counts", None) is None or self._mat_counts.numel() < n_chunks:
+            self._mat_counts = torch.zeros(max(n_chunks, 16), device=self.device, dtype=torch.int32)
+        s, hid, out = self._stream(), self._mat_hidden, self._mat_logits
+        if n_chunks > 1:
+            _lib.call("coda_chunk_counts", _ptr(self.count), chunk, n_chunks, _ptr(self._mat_counts), s)
+        for c in range(n_chunks):
+            rows = min(chunk, max_rows - c * chunk)
+            cnt = _ptr(self.count) if n_chunks == 1 else _ptr(self._mat_counts) + 4 * c
+            _lib.call("coda_gather_rows", _ptr(self.hn), self.hn.stride(0), _ptr(self.src_rows) + 4 * c * chunk, cnt, rows,
+                      _ptr(hid), hid.stride(0), self.H, s)
+            _lib.call("coda_gemm_bf16_counted", _ptr(hid), hid.stride(0), cnt, _ptr(self.lm_head), self.lm_head.stride(0),
+                      _ptr(out), out.stride(0), rows, self.V, self.H, s)
+            _lib.call("coda_confidence_from_logits", _ptr(out), out.stride(0), 1, rows, self.V, cnt,
+                      _ptr(self.dst_pos) + 4 * c * chunk, alg, float(temperature), 0.0, 0,
+                      None if noise is None else _ptr(noise) + 4 * c * chunk * self.V, seed, int(round_conf),
+                      _ptr(self.conf), _ptr(self.x0), s)
 
     @_on_device
     def candidate_logits(self, max_rows: int) -> torch.Tensor:

@@ -114,6 +114,11 @@ int coda_gather_rows(const void* src, long long ld_src, const int* rows, const i
 int coda_gemm_bf16_counted(const void* X, long long ldx, const int* m_count, const void* W, long long ldw, void* C,
                            long long ldc, int M_max, int N, int K, void* stream);
 
+/* out[c] = clamp(count[0] - c * chunk, 0, chunk) for c < n_chunks: the device-side row counts of the chunks when a long
+ * candidate list goes through coda_gather_rows / coda_gemm_bf16_counted / coda_confidence_from_logits chunk by chunk
+ * (`logits[mask_index]` of generation_utils.py:457 with a bounded logits buffer; no counterpart line in the reference). */
+int coda_chunk_counts(const int* count, int chunk, int n_chunks, int* out, void* stream);
+
 /* Inverse of coda_gather_rows: dst[rows[i]] = src[i] for i < n (rows outside [0, dst_rows) are skipped), H bf16 per row.
  * Used by the last decoder layer's compact tail: only the hidden rows whose logits the sampler consumes
  * (generation_utils.py:457,462: positions p-1 of the candidate positions p) go through o_proj / the MLP / the final

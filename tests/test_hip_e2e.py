@@ -223,6 +223,32 @@ def test_last_layer_compact_tail_same_tokens(small, mid, block_length):
         assert all(torch.equal(u, v) for u, v in zip(a.history, b.history))
 
 
+@pytest.mark.parametrize("temperature", [0.0, 0.8])
+def test_lmhead_routes_agree(small, mid, temperature):
+    """engine.lmhead_confidence has two routes to the same numbers: the fused kernel (few candidate rows) and, from
+    engine.materialise_min_rows on, row gather + counted GEMM + confidence kernel over a chunked bf16 logits buffer (faster
+    for long candidate lists).  Forced both ways, with chunks so small that a step needs several and the last is ragged:
+    same tokens, same histories - greedy and with the in-kernel noise (same hash keys on both routes)."""
+    for d, sd, m in (small, mid):
+        eng = m.hip_engine()
+        g = torch.Generator().manual_seed(29)
+        ids = torch.randint(0, d.pad_id, (5, 20), generator=g).to(DEV)
+        kw = dict(max_new_tokens=24, steps=12, alg="topk_margin", alg_temp=0.2, temperature=temperature,
+                  mask_token_id=d.mask_id, return_dict_in_generate=True, output_history=True)
+        keep = (eng.materialise_min_rows, eng.logits_chunk_rows)
+        outs = []
+        try:
+            for min_rows, chunk in ((1 << 30, 8192), (1, 8192), (1, 56)):
+                eng.materialise_min_rows, eng.logits_chunk_rows = min_rows, chunk
+                torch.manual_seed(1234)                      # the run's noise seed is drawn from torch's CPU generator
+                outs.append(m.diffusion_generate(ids, **kw))
+        finally:
+            eng.materialise_min_rows, eng.logits_chunk_rows = keep
+        for o in outs[1:]:
+            assert torch.equal(o.sequences, outs[0].sequences)
+            assert all(torch.equal(u, v) for u, v in zip(o.history, outs[0].history))
+
+
 def test_fused_equals_materialised_path(small):
     d, sd, m = small
     g = torch.Generator().manual_seed(5)

@@ -36,7 +36,9 @@ CONFIGS = [
     # top_p=0.9, entropy); the first steps (every generated position still masked) are the expensive ones
     ("E1 lm-eval", 32, 128, 768, 768, None, dict(alg="entropy", temperature=0.1, top_p=0.9, alg_temp=0.0), 8),
 ]
-only = sys.argv[1:] 
+if os.environ.get("FUSED") == "1":              # A/B: the fused lm-head kernel at every row count (engine.materialise_min_rows)
+    model.hip_engine().materialise_min_rows = 1 << 30
+only = sys.argv[1:]
 for name, B, P, G, steps, bl, kw, run in CONFIGS:
     if only and not any(o in name for o in only):
         continue
