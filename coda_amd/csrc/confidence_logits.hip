@@ -123,13 +123,66 @@ __global__ __launch_bounds__(256) void confidence_kernel(ConfArgs a) {
         for (int v = nvec * per + tid; v < V; v += 256) fn(v, logit(v));
     };
 
+    const bool use_p = a.top_p > 0.f && a.top_p < 1.f;
+    const bool use_k = a.top_k > 0 && a.top_k < V;
+
+    if (!use_p && !use_k && !sampled) {
+        // ---- greedy, nothing filtered (the materialised lm-head route of long candidate lists): ONE pass over the row.
+        // Every thread keeps an online softmax of its own entries - maximum, second maximum (duplicates counted), first
+        // index of the maximum, sum e^(x-m) and sum e^(x-m)(x-m) relative to ITS running maximum, rescaled on the rare
+        // step up - and the 256 partial states are merged once.  The row is read from memory once instead of twice.
+        float m = -INFINITY, m2 = -INFINITY, z = 0.f, s = 0.f;
+        int arg = 0x7fffffff;
+        for_each([&](int v, float x) {
+            if (x > m) {
+                if (z > 0.f) {
+                    const float d = m - x, sc = __expf(d);
+                    s = sc * (s + d * z);
+                    z *= sc;
+                }
+                z += 1.0f;
+                m2 = m;
+                m = x;
+                arg = v;
+            } else if (x > -INFINITY) {                  // (-inf entries - banned by a logits hook - carry nothing)
+                const float d = x - m, e = __expf(d);
+                z += e;
+                s += e * d;
+                m2 = fmaxf(m2, x);
+                if (x == m) arg = min(arg, v);
+            }
+        });
+        const float mx = block_reduce<float>(m, red_f, tid, fmax_op);
+        const bool top = m == mx;
+        float zt = 0.f, st = 0.f;
+        if (z > 0.f) {
+            const float d = m - mx, sc = __expf(d);
+            zt = z * sc;
+            st = sc * (s + d * z);
+        }
+        zt = block_reduce<float>(zt, red_f, tid, fadd_op);
+        st = block_reduce<float>(st, red_f, tid, fadd_op);
+        const int holders = block_reduce<int>(top ? 1 : 0, red_i, tid, iadd_op);
+        float r2 = block_reduce<float>(top ? m2 : m, red_f, tid, fmax_op);
+        if (holders > 1) r2 = mx;
+        const int rarg = block_reduce<int>(top ? arg : 0x7fffffff, red_i, tid, imin_op);
+        if (tid == 0) {
+            float c;
+            if (a.alg == CODA_ALG_TOPK_MARGIN) c = (1.0f - __expf(r2 - mx)) / zt;
+            else if (a.alg == CODA_ALG_ENTROPY) c = st / zt - __logf(zt);
+            else c = 1.0f / zt;
+            if (a.round_conf) c = round_bf16(c);
+            const int at = a.dst_pos ? a.dst_pos[row] : row;
+            a.conf[at] = c;
+            a.x0[at] = rarg;
+        }
+        return;
+    }
+
     // ---- softmax statistics of the unfiltered row (needed by top-p)
     float mx = -INFINITY;
     for_each([&](int, float x) { mx = fmaxf(mx, x); });
     mx = block_reduce<float>(mx, red_f, tid, fmax_op);
-
-    const bool use_p = a.top_p > 0.f && a.top_p < 1.f;
-    const bool use_k = a.top_k > 0 && a.top_k < V;
     unsigned int kp = 0u;        // top-p threshold key (keep key > kp, ties by index up to p_cut)
     int p_cut = 0x7fffffff;      // among key == kp keep indices <= p_cut
     unsigned int kk = 0u;        // top-k threshold key (keep key >= kk)

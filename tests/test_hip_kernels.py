@@ -763,6 +763,30 @@ def test_confidence_top_p_single_token_nucleus_shortcut():
     assert c[3] == 1.0 and c[4] == 1.0 and c[5] == 1.0 and abs(c[2] - 0.8995) < 1e-3 and abs(c[6] - 0.5) < 1e-4 and c[7] == 1.0
 
 
+def test_confidence_greedy_single_pass_ties_and_banned_entries():
+    """Greedy, nothing filtered: the kernel reads the row once (per-thread online softmax, merged).  bf16 rows tie massively:
+    the token is the FIRST index of the maximum, the margin is 0 when the maximum is duplicated (anywhere in the row: same
+    thread's stride or another's), -inf entries carry nothing; all three confidences against the oracle."""
+    g = torch.Generator().manual_seed(23)
+    N, V = 12, 151936
+    logits = (torch.randn(N, V, generator=g) * 2).to(BF).float()
+    logits[0, 777] = logits[0].max()                        # a second maximum somewhere else
+    mx1 = logits[1].max()
+    logits[1, 5] = mx1
+    logits[1, 5 + 256] = mx1                                # ... in the same thread's stride (entries v, v + 256 * k)
+    logits[2, :4096] = -math.inf                            # banned head of the row
+    logits[3, 100000:] = -math.inf
+    logits[4] = 1.5                                         # all equal
+    for alg_id, okw in ((0, {}), (1, dict(margin=True)), (2, dict(neg_entropy=True))):
+        c_ref, x_ref = ref_cpu.sample_tokens(logits, 0.0, **okw)
+        for lg in (logits, logits.to(BF)):
+            conf, x0 = _conf_logits(lg, alg_id)
+            assert torch.equal(x0, x_ref), alg_id
+            assert (conf - c_ref).abs().max() < 2e-4, (alg_id, (conf - c_ref).abs().max())
+    c, _ = _conf_logits(logits, 1)
+    assert c[0] == 0.0 and c[1] == 0.0 and c[4] == 0.0      # duplicated maximum: margin 0
+
+
 def test_confidence_from_logits_bf16_ties():
     """bf16 logits tie massively; the kept sets of top-p / top-k must follow the documented rule
     (ties at the top-p boundary enter in index order, ties at the k-th value are all kept)."""
