@@ -247,6 +247,27 @@ def test_lmhead_routes_agree(small, mid, temperature):
         for o in outs[1:]:
             assert torch.equal(o.sequences, outs[0].sequences)
             assert all(torch.equal(u, v) for u, v in zip(o.history, outs[0].history))
+    if temperature > 0:
+        # injected token noise (one [candidates, V] tensor per step): every chunk must read its own rows of it
+        d, sd, m = small
+        eng = m.hip_engine()
+        g = torch.Generator().manual_seed(7)
+        ids = torch.randint(0, d.pad_id, (3, 8), generator=g)
+        kw = dict(max_new_tokens=16, steps=8, alg="maskgit_plus", temperature=temperature)
+        torch.manual_seed(123)
+        noise = ref_cpu.TorchNoise()
+        ref_cpu.diffusion_generate(sd, d, ids, noise=noise, **kw)
+        keep = (eng.materialise_min_rows, eng.logits_chunk_rows)
+        outs = []
+        try:
+            for min_rows, chunk in ((1 << 30, 8192), (1, 20)):
+                eng.materialise_min_rows, eng.logits_chunk_rows = min_rows, chunk
+                outs.append(m.diffusion_generate(ids.to(DEV), mask_token_id=d.mask_id, noise_source=Replay(noise.log, d.vocab),
+                                                 return_dict_in_generate=True, output_history=True, **kw))
+        finally:
+            eng.materialise_min_rows, eng.logits_chunk_rows = keep
+        assert torch.equal(outs[0].sequences, outs[1].sequences)
+        assert all(torch.equal(u, v) for u, v in zip(outs[0].history, outs[1].history))
 
 
 def test_fused_equals_materialised_path(small):
