@@ -37,6 +37,15 @@ for B, L in ((32, 384), (64, 768), (8, 2048)):
         torch.cuda.synchronize()
         outs[name] = out
         times[name] = (go, [])
+    out2 = torch.empty(T, N, device=DEV, dtype=BF)
+
+    def go_unfused():
+        _lib.call("coda_gemm_bf16", X.data_ptr(), K, None, W.data_ptr(), K, out2.data_ptr(), N, None, 0, T, N, K, 0, s)
+        _lib.call("coda_qknorm_rope", out2.data_ptr(), N, qw.data_ptr(), kw.data_ptr(), cos.data_ptr(), sin.data_ptr(), T, L,
+                  n_q, n_kv, 1e-6, s)
+    go_unfused()
+    torch.cuda.synchronize()
+    times["gemm + qknorm_rope"] = (go_unfused, [])
     for rnd in range(5):
         for name, (go, ts) in times.items():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -51,4 +60,4 @@ for B, L in ((32, 384), (64, 768), (8, 2048)):
     same = (a == b).float().mean().item()
     fl = 2.0 * T * N * K
     print(f"T={T} L={L}: " + " | ".join(f"{n} {sorted(ts)[2]*1e3:7.1f} us {fl/sorted(ts)[2]/1e9:6.0f} TF" for n, (g, ts) in times.items())
-          + f" | outputs equal {same:.5f}", flush=True)
+          + f" | outputs equal {same:.5f}, unfused equal {(out2 == b).float().mean().item():.5f}", flush=True)
