@@ -933,7 +933,7 @@ def test_in_kernel_sampling_follows_the_softmax(top_p, top_k):
     cnt = torch.tensor([N], dtype=torch.int32, device=DEV)
     draws = {"unfused": [], "fused": []}
     for k in range(n_seeds):
-        seed = 0x5EED_0000_0000 + 7919 * k
+        seed = (0x5EED_0000_0000 + 0x9E3779B97F4A7C15 * (k + 1)) & 0xFFFFFFFFFFFFFFFF     # DeviceNoise.step_seed's stepping
         conf = torch.empty(N, device=DEV)
         x0 = torch.empty(N, device=DEV, dtype=torch.int64)
         _lib.call("coda_confidence_from_logits", _p(logits), V, 1, N, V, None, None, 0, T, top_p, top_k, None, seed, 0, _p(conf), _p(x0), _s())
@@ -977,7 +977,7 @@ def test_in_kernel_selection_and_origin_noise_distributions():
     for k in range(8):
         xd = x.to(DEV)
         _lib.call("coda_select_unmask", _p(xd), _p(conf), _p(x0.to(DEV)), _p(cnt), B, L, 0, L, mask_id, 0.13, 0, alg_temp, None,
-                  0xABCD_0000 + 104729 * k, None, _s())
+                  (0xABCD_0000 + 0x9E3779B97F4A7C15 * (k + 1)) & 0xFFFFFFFFFFFFFFFF, None, _s())
         torch.cuda.synchronize()
         changed = xd.cpu() != mask_id
         assert (changed.sum(1) == 1).all()
