@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--layers", type=int, default=28, help="debug only; anything but 28 marks the line invalid")
     ap.add_argument("--cpu-steps", type=int, default=12, help="denoise steps timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--lmhead-materialise-from", type=int, default=None,
+                    help="A/B only: candidate-row bound from which the lm-head takes the materialised route (engine default otherwise)")
     ap.add_argument("--stub-cpu", action="store_true", help="tests only: gloo ranks on the CPU around a stub generate")
     args = ap.parse_args()
 
@@ -196,6 +198,8 @@ def main():
     gen = dict(max_new_tokens=G, steps=S, alg="entropy", temperature=0.0, block_length=bl, mask_token_id=cfg.mask_token_id)
 
     eng = model.hip_engine()
+    if args.lmhead_materialise_from is not None:
+        eng.materialise_min_rows = args.lmhead_materialise_from
 
     def sync():
         if dev.type == "cuda":
