@@ -239,11 +239,26 @@ def sample_tokens(logits: torch.Tensor, temperature: float = 0.0, top_p=None, to
         if diag is not None and probs.shape[0]:
             t2 = torch.topk(logits.float(), 2, dim=-1)[0]
             diag["gap"] = (t2[:, 0] - t2[:, 1]) / t2[:, 0].abs().clamp_min(1e-30)
+            diag["gap_abs"] = t2[:, 0] - t2[:, 1]          # distance of the two largest logits, in logit units
     if diag is not None and probs.shape[0]:
         live = logits.float()
         live = live.masked_fill(live <= torch.finfo(logits.dtype).min, 0.0)     # entries removed by top-p / top-k
         diag["absmax"] = live.abs().max(dim=-1)[0]
         diag["pmax"] = probs.float().max(dim=-1)[0]
+        # sensitivity of the confidence to the softmax inputs: sum_v |d conf / d l_v| (fp32, from this row's own
+        # probabilities).  A perturbation of the inputs bounded by u / 2 around a common shift (softmax is shift
+        # invariant) moves the confidence by at most (u / 2) * sens to first order - the parity tests' tight tolerance.
+        p32 = torch.softmax(logits.float(), dim=-1)
+        if neg_entropy:
+            lp = torch.log(p32.clamp_min(1e-38))
+            h32 = (p32 * lp).sum(-1, keepdim=True)
+            diag["sens"] = (p32 * (lp - h32).abs()).sum(-1)
+        elif margin:
+            t2p = torch.topk(p32, 2, dim=-1)[0]
+            diag["sens"] = 2 * t2p[:, 0] * (1 - t2p[:, 0]) + 2 * t2p[:, 1] * (1 - t2p[:, 1])
+        else:
+            px = p32.gather(-1, x0[:, None]).squeeze(-1)
+            diag["sens"] = 2 * px * (1 - px)
     if margin:
         top2 = torch.sort(probs, dim=-1, descending=True)[0][:, :2]
         conf = top2[:, 0] - top2[:, 1]
@@ -299,6 +314,8 @@ class SamplerTrace:
     absmax: List[torch.Tensor] = field(default_factory=list)     # largest |logit| of every candidate row
     nucleus: List[Optional[torch.Tensor]] = field(default_factory=list)   # top-p only: [n, V] mass before each token
     pmax: List[torch.Tensor] = field(default_factory=list)       # largest probability of every candidate row
+    gap_abs: List[Optional[torch.Tensor]] = field(default_factory=list)   # greedy: top-2 logit distance, logit units
+    sens: List[Optional[torch.Tensor]] = field(default_factory=list)      # sum_v |d conf / d logit_v| of every row
 
 
 def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.Tensor,
@@ -374,7 +391,7 @@ def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: to
                     gap[pick] = dg["gap"]
                 tr.x0.append(x0.clone()); tr.gap.append(gap); tr.cand.append(mask_index.clone())
                 tr.key.append(None); tr.k.append(None); tr.absmax.append(None); tr.conf.append(None); tr.pmax.append(None)
-                tr.nucleus.append(None)
+                tr.nucleus.append(None); tr.gap_abs.append(None); tr.sens.append(None)
         elif args.alg == "confidence_threshold":
             # serving/dream/model/generation_utils.py:442-465 (the serving sampler bound onto the CoDA model by
             # serving/fast-api/app/core/service.py:99-120)
@@ -407,6 +424,7 @@ def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: to
                 tr.chosen.append(transfer.nonzero()); tr.key.append(full.float()); tr.cand.append(mask_index.clone())
                 tr.gap.append(dg.get("gap", torch.zeros(0))); tr.absmax.append(dg.get("absmax", torch.zeros(0)))
                 tr.pmax.append(dg.get("pmax", torch.zeros(0))); tr.nucleus.append(dg.get("nucleus_excl"))
+                tr.gap_abs.append(dg.get("gap_abs")); tr.sens.append(dg.get("sens"))
         else:
             if args.alg not in ("maskgit_plus", "topk_margin", "entropy"):
                 raise RuntimeError(f"Unknown alg: {args.alg}")
@@ -438,6 +456,7 @@ def sample_loop(logits_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: to
                 tr.key.append(sel_key.float().masked_fill(~mask_index, -torch.inf)); tr.cand.append(mask_index.clone())
                 tr.gap.append(dg.get("gap", torch.zeros(0))); tr.absmax.append(dg.get("absmax", torch.zeros(0)))
                 tr.pmax.append(dg.get("pmax", torch.zeros(0))); tr.nucleus.append(dg.get("nucleus_excl"))
+                tr.gap_abs.append(dg.get("gap_abs")); tr.sens.append(dg.get("sens"))
         if tokens_hook is not None:
             x = tokens_hook(i, x, logits)
         if args.output_history or trace:

@@ -15,6 +15,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+EXCUSED_SMALL = 0.08    # bound on the share of tokens the near-tie band may excuse on the 2- / 3-layer models (measured <= 2.5 %; T = 0.1 + top-p: 1.3 %)
 
 from coda_amd import CoDAConfig, CoDALanguageModel, DLMGenerationConfig  # noqa: E402
 from oracle import ref_cpu  # noqa: E402
@@ -76,12 +77,21 @@ def test_forward_logits_vs_oracle(small, mid):
         assert err.max().item() < 0.08 * scale
         agree = (out.float().cpu().argmax(-1) == ref.argmax(-1)).float().mean().item()
         assert agree > 0.97, agree
+        # the same deviation in the unit tests/parity.py states its bands in: bf16 ulps of the row's largest |logit|
+        from parity import FWD_ERR_ULPS_SMALL, bf16_ulp
+        ulp = bf16_ulp(ref.abs().amax(-1, keepdim=True))
+        eu = err / ulp
+        top = eu[ref >= ref.amax(-1, keepdim=True) - 16 * ulp]
+        kth = lambda t, q: float(torch.kthvalue(t.reshape(-1), max(1, int(q * t.numel())))[0])
+        print(f"   in bf16 ulps of the row's largest |logit| ({d.layers} layers): mean {eu.mean():.3f} p99.9 {kth(eu, 0.999):.2f} max {eu.max():.2f}; "
+              f"near the row maximum ({top.numel()} logits) p99.9 {kth(top, 0.999):.2f} max {top.max():.2f}")
+        assert kth(top, 0.999) <= FWD_ERR_ULPS_SMALL and kth(eu, 0.999) <= 1.25 * FWD_ERR_ULPS_SMALL
 
 
 @pytest.mark.parametrize("alg", ["entropy", "maskgit_plus", "topk_margin"])
 @pytest.mark.parametrize("block_length", [None, 8])
 def test_greedy_generate_teacher_forced(small, alg, block_length):
-    from parity import describe, teacher_forced
+    from parity import assert_parity, describe, teacher_forced
     d, sd, m = small
     g = torch.Generator().manual_seed(3)
     ids = torch.randint(0, d.pad_id, (4, 24), generator=g)
@@ -96,7 +106,7 @@ def test_greedy_generate_teacher_forced(small, alg, block_length):
     assert (out.sequences != d.mask_id).all()
     stats, tr = teacher_forced(sd, d, ids, hist, trace, block_length=block_length, **kw)
     print(f"teacher-forced {alg} bl={block_length}: {describe(stats)}")
-    assert not stats["violations"], stats["violations"][:5]
+    assert_parity(stats, max_excused=EXCUSED_SMALL)
 
 
 def test_golden_free_running(small, golden):
@@ -362,12 +372,12 @@ def test_stochastic_with_injected_noise(small, cfg):
     trace = []
     out = m.diffusion_generate(ids.to(DEV), mask_token_id=d.mask_id, noise_source=Replay(noise.log, d.vocab),
                                return_dict_in_generate=True, output_history=True, debug_trace=trace, **kw)
-    from parity import describe, teacher_forced
+    from parity import assert_parity, describe, teacher_forced
     hist = [h.cpu() for h in out.history]
     stats, tr = teacher_forced(sd, d, ids, hist, trace, noise_log=noise.log, **kw)
     rate = (out.sequences.cpu() == ref.sequences).float().mean().item()
     print(f"stochastic {cfg}: free-running token match {rate:.3f}; teacher-forced {describe(stats)}")
-    assert not stats["violations"], stats["violations"][:5]
+    assert_parity(stats, max_excused=EXCUSED_SMALL)
 
 
 def test_device_rng_is_reproducible(small):
@@ -390,7 +400,7 @@ def test_lm_eval_adapter_left_padded(small, temperature):
     and cut to max_prompt_len, attention_mask passed, top_p = 0.9 with T = 0 (deterministic) and the eval scripts'
     T = 0.1 (noise replayed from the oracle)."""
     from coda_amd.lm_eval_adapter import DiffLLMAdapter
-    from parity import describe, teacher_forced
+    from parity import assert_parity, describe, teacher_forced
     d, sd, m = small
     g = torch.Generator().manual_seed(77)
     prompts = [torch.randint(0, d.pad_id, (n,), generator=g).tolist() for n in (9, 4, 12, 1)]
@@ -411,7 +421,7 @@ def test_lm_eval_adapter_left_padded(small, temperature):
     assert (out.sequences[:, :10] == ids).all() and (out.sequences != d.mask_id).all()
     stats, _ = teacher_forced(sd, d, ids.cpu(), [h.cpu() for h in out.history], trace, noise_log=log, **kw)
     print(f"lm-eval shape T={temperature}: {describe(stats)}")
-    assert not stats["violations"], stats["violations"][:5]
+    assert_parity(stats, max_excused=EXCUSED_SMALL)
     if temperature == 0:
         resp = a.generate_batch_ids(prompts)
         eos = d.pad_id + 1
@@ -430,7 +440,7 @@ def test_confidence_threshold_serving_alg(small, cfg):
     """the serving sampler's confidence_threshold alg (serving/dream/model/generation_utils.py:416-465),
     one sequence, data-dependent step count; teacher-forced against the oracle, bookkeeping replayed on HIP confidences."""
     from coda_amd.serving import SamplerService
-    from parity import describe, teacher_forced
+    from parity import assert_parity, describe, teacher_forced
     d, sd, m = small
     g = torch.Generator().manual_seed(52)
     ids = torch.randint(0, d.pad_id, (1, 7), generator=g)
@@ -449,7 +459,7 @@ def test_confidence_threshold_serving_alg(small, cfg):
     assert (out.sequences != d.mask_id).all() and len(hist) >= cfg["steps"] and len(trace) == len(hist)
     stats, _ = teacher_forced(sd, d, ids, hist, trace, noise_log=log, **kw)
     print(f"confidence_threshold {cfg}: {len(hist)} steps used; {describe(stats)}")
-    assert not stats["violations"], stats["violations"][:5]
+    assert_parity(stats, max_excused=EXCUSED_SMALL)
     if cfg["temperature"] == 0:
         # the serving mirror returns the same completion, mask/pad ids dropped
         svc = SamplerService(m, mask_token_id=d.mask_id)
