@@ -13,8 +13,9 @@ vector per rank (evaluation/lm_eval/lm_eval/evaluator.py:523-526,620-642).  Rank
 N ranks come about in either of two ways:
   * under a launcher (``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``): RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* are in the environment and this process is one rank;
-  * ``python bench.py --gpus N`` on its own: this process is only a PARENT - it touches no GPU, starts N children (one
-    per device, the environment above set for each), waits for them and exits with their status.
+  * ``python bench.py --gpus N`` on its own: this process is only a PARENT - it makes no HIP call at all (no device
+    count either), starts N children (one per device, the environment above set for each), waits for them and exits with
+    their status.  Profile with ``--gpus 1`` (or a pre-launched rank): under rocprofv3 the parent would be a launcher hop.
 ``n_gpus`` in the line is the world size the process group itself reports.
 """
 import argparse
@@ -144,8 +145,8 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        if not args.stub_cpu and os.environ.get("CODA_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < args.gpus:
-            sys.exit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+        # the parent makes NO HIP call, not even a device count (on ROCm that initialises the runtime): a rank whose
+        # device does not exist fails in its own process and takes the others down (spawn_ranks)
         sys.exit(spawn_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -282,15 +283,20 @@ def main():
             line["kernels"] = summ
             dom = summ.get("gate_up")
             if dom:
-                traffic = mfma_busy = None
+                # NOT measured in this run: PMC counters need their own rocprofv3 passes (tools/prof_passes.sh,
+                # tools/mfma_pmc.sh); the committed reduction of the latest such passes is carried along, with its source
+                traffic = mfma_busy = traffic_src = mfma_src = None
                 tpath = os.path.join(ROOT, "profiles", "traffic.json")
                 if os.path.exists(tpath):
                     tj = json.load(open(tpath))
                     traffic, mfma_busy = tj.get("gate_up_hbm_bytes_per_launch"), tj.get("gate_up_mfma_util")
+                    traffic_src, mfma_src = tj.get("source"), tj.get("gate_up_mfma_util_source")
                 line["roofline"] = {"bound": "mfma", "kernel": "gemm256w4_bf16_kernel<SWIGLU> (gate|up projection + SiLU*up, four-wave persistent 256x256 engine)",
                                     "mfma_busy_pmc": mfma_busy,
                                     "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                     "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
+                                    "traffic_source": f"{traffic_src} (rocprofv3 --pmc passes of an earlier run of this command, not this run)",
+                                    "mfma_busy_pmc_source": mfma_src,
                                     "avg_launch_ms": dom["avg_ms"], "flops_per_launch": dom["flops_per_launch"],
                                     "launches_timed": dom["launches"]}
         if world == 1 and args.cpu_steps > 0 and not args.stub_cpu:

@@ -19,6 +19,7 @@ _p, _i, _ll, _f, _ull = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes
 SIGNATURES = {
     "coda_version": (_i, []),
     "coda_last_error": (ctypes.c_char_p, []),
+    "coda_temperature_fast_division": (_i, [_f]),
     "coda_embed_gather": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "coda_rmsnorm": (_i, [_p, _ll, _p, _p, _ll, _i, _i, _f, _p]),
     "coda_gemm_bf16": (_i, [_p, _ll, _p, _p, _ll, _p, _ll, _p, _ll, _i, _i, _i, _i, _p]),

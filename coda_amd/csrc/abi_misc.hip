@@ -57,3 +57,42 @@ int coda_ensure_dyn_lds(const void* func, int bytes) {
     }
     return CODA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// coda_div_by's licence (coda_common.h): the sequence is run here exactly as the device runs it (fp32 multiply, two fused
+// multiply-adds) for every bf16 x in its fast-path domain and compared with the IEEE quotient.  A read-once fact per
+// temperature, like the CU count: results never depend on whether it is cached.
+#include <math.h>
+#include <string.h>
+namespace {
+std::mutex g_rcp_mu;
+std::vector<std::pair<float, float>> g_rcp;      // (t, rt or 0)
+}
+
+float coda_reciprocal_if_exact(float t) {
+    if (!(t > 0.f) || !(t >= 1e-3f && t <= 1e3f)) return 0.f;
+    {
+        std::lock_guard<std::mutex> lk(g_rcp_mu);
+        for (auto& e : g_rcp)
+            if (e.first == t) return e.second;
+    }
+    const float rt = (float)(1.0 / (double)t);
+    bool exact = true;
+    for (unsigned int b = 0; b < 65536u && exact; ++b) {
+        const unsigned int bits = b << 16;
+        float x;
+        memcpy(&x, &bits, 4);
+        if (!coda_div_fast_domain(bits)) continue;                      // the device divides there
+        volatile float q0 = x * rt;                                       // volatile: one fp32 rounding per operation
+        volatile float r = fmaf(-q0, t, x);
+        volatile float q1 = fmaf(r, rt, q0);
+        volatile float q = x / t;
+        if (!(q1 == q)) exact = false;
+    }
+    const float out = exact ? rt : 0.f;
+    std::lock_guard<std::mutex> lk(g_rcp_mu);
+    if (g_rcp.size() < 4096) g_rcp.emplace_back(t, out);
+    return out;
+}
+
+extern "C" int coda_temperature_fast_division(float temperature) { return coda_reciprocal_if_exact(temperature) != 0.f ? 1 : 0; }

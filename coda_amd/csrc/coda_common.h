@@ -61,15 +61,28 @@ __device__ __forceinline__ float coda_hash_uniform(unsigned int seed_lo, unsigne
 }
 
 // x / t for a loop-invariant divisor, correctly rounded like the IEEE quotient (what `logits / temperature` is in the
-// reference), in three operations instead of the ~12 of a full division: with rt = RN(1 / t) computed once on the host in
-// double, q0 = RN(x rt), r = x - q0 t (exact in one FMA), q1 = RN(q0 + r rt) is the correctly rounded quotient
-// (Markstein's division theorem; tests/test_host_logic.py checks it against exact rational arithmetic for every bf16 x
-// and the temperatures of the configurations).  Infinities pass through (a logits hook may ban tokens with -inf).
+// reference), in three operations instead of the ~12 of a full division: q0 = RN(x rt), r = x - q0 t (exact in one FMA),
+// q1 = RN(q0 + r rt) with rt = RN(1 / t).  Markstein's sequence gives the correctly rounded quotient for MOST (x, t), not
+// all (rt is rounded twice, from double; exceptional pairs exist), so the fast form is used only where it has been
+// VERIFIED: `rt` comes from coda_reciprocal_if_exact(t) (abi_misc.hip), which runs the sequence on the host for every
+// bf16 x in the fast-path domain below against the IEEE quotient and returns 0 if a single one differs - and 0 for fp32
+// logits, whose x are not enumerable.  rt == 0, or an x outside the domain (quotient or intermediate could leave the
+// normal range; +-inf from a logits hook that bans tokens), takes the true division.
+// fast-path domain of coda_div_by: +-0, or a biased exponent in [28, 226), i.e. 2^-99 <= |x| < 2^99 (quotient and
+// intermediates stay normal for every licensed t in [1e-3, 1e3]); the host check enumerates exactly this set
+__host__ __device__ __forceinline__ bool coda_div_fast_domain(unsigned int bits) {
+    const unsigned int e = (bits >> 23) & 0xffu;
+    return (e - 28u) < 198u || (bits << 1) == 0u;
+}
+
 __device__ __forceinline__ float coda_div_by(float x, float t, float rt) {
     const float q0 = x * rt;
     const float r = __builtin_fmaf(-q0, t, x);
-    const float q1 = __builtin_fmaf(r, rt, q0);
-    return __builtin_isinf(x) ? x : q1;
+    float q = __builtin_fmaf(r, rt, q0);
+    // rare: rt == 0 is uniform over the launch (temperature not licensed / fp32 logits); the domain test fails only for
+    // values no logit has (|x| >= 2^99, denormal-range quotients, +-inf from a hook that bans tokens)
+    if (__builtin_expect(rt == 0.f || !coda_div_fast_domain(__float_as_uint(x)), 0)) q = __fdiv_rn(x, t);
+    return q;
 }
 
 // Exponential race with coda_hash_uniform noise: key = logit - log(-log(u)), u in [2^-24, 1 - 2^-24], so the noise term

@@ -437,7 +437,8 @@ extern "C" int coda_confidence_from_logits(const void* logits, long long ld, int
     ConfArgs a;
     a.logits = (const char*)logits; a.ld_b = ld * (is_bf16 ? 2 : 4); a.is_bf16 = is_bf16;
     a.N = N; a.V = V; a.count = count; a.dst_pos = dst_pos;
-    a.alg = alg; a.temperature = temperature; a.inv_temperature = temperature > 0.f ? (float)(1.0 / (double)temperature) : 0.f; a.top_p = top_p; a.top_k = top_k;
+    a.alg = alg; a.temperature = temperature; a.top_p = top_p; a.top_k = top_k;
+    a.inv_temperature = (temperature > 0.f && is_bf16) ? coda_reciprocal_if_exact(temperature) : 0.f;   // 0: true division
     a.noise = noise; a.seed_lo = (unsigned int)seed; a.seed_hi = (unsigned int)(seed >> 32);
     a.round_conf = round_conf_bf16; a.conf = conf; a.x0 = x0;
     hipLaunchKernelGGL(confidence_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, a);

@@ -59,7 +59,7 @@ struct LmArgs {
     const char* hidden; long long ldh_b;
     const int* src_rows; const int* dst_pos; const int* count;
     const char* W; long long ldw_b;
-    int V, H, alg;
+    int V, H, alg, max_rows;
     float temperature, inv_temperature;
     const float* noise;
     unsigned int seed_lo, seed_hi;
@@ -75,8 +75,8 @@ __global__ __launch_bounds__(256) void lmhead_partial_kernel(LmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n = a.count[0];
-    if (n <= 0) return;
+    const int n = min(a.count[0], a.max_rows);       // the records and conf / x0 are sized for max_rows: a larger device-side
+    if (n <= 0) return;                              // count must not write past them (confidence_kernel clamps the same way)
     const int tiles_total = (a.V + BN - 1) / BN;
     int active_rb, vsplits;
     split_geometry(n, tiles_total, active_rb, vsplits);
@@ -198,10 +198,10 @@ __global__ __launch_bounds__(256) void lmhead_partial_kernel(LmArgs a) {
 
 // One wave per candidate row: lanes stride over the vocab splits, then a shuffle tree merges them.
 __global__ __launch_bounds__(256) void lmhead_combine_kernel(const float* __restrict__ part, const int* __restrict__ count,
-                                                             const int* __restrict__ dst_pos, int V, int alg, int sampled,
-                                                             int round_bf16_conf, float* __restrict__ conf,
+                                                             const int* __restrict__ dst_pos, int max_rows, int V, int alg,
+                                                             int sampled, int round_bf16_conf, float* __restrict__ conf,
                                                              long long* __restrict__ x0) {
-    const int n = count[0];
+    const int n = min(count[0], max_rows);           // same clamp as lmhead_partial_kernel: same split geometry
     const int tiles_total = (V + BN - 1) / BN;
     int active_rb, vsplits;
     split_geometry(n, tiles_total, active_rb, vsplits);
@@ -257,7 +257,7 @@ static int lmhead_launch(const void* hidden, long long ld_hidden, const int* src
     a.hidden = (const char*)hidden; a.ldh_b = ld_hidden * 2;
     a.src_rows = src_rows; a.dst_pos = dst_pos; a.count = count;
     a.W = (const char*)W; a.ldw_b = ldw * 2;
-    a.V = V; a.H = H; a.alg = alg; a.temperature = temperature; a.inv_temperature = temperature > 0.f ? (float)(1.0 / (double)temperature) : 0.f;
+    a.V = V; a.H = H; a.alg = alg; a.max_rows = max_rows; a.temperature = temperature; a.inv_temperature = temperature > 0.f ? coda_reciprocal_if_exact(temperature) : 0.f;   // 0: true division
     a.noise = noise;
     a.seed_lo = (unsigned int)seed; a.seed_hi = (unsigned int)(seed >> 32);
     a.part = (float*)part;
@@ -265,8 +265,8 @@ static int lmhead_launch(const void* hidden, long long ld_hidden, const int* src
     hipLaunchKernelGGL(lmhead_partial_kernel, dim3(LM_GRID), dim3(256), LDS_BYTES, s, a);
     CODA_CHECK_LAUNCH("lmhead_partial");
     const int cgrid = max(1, min(2048, (max_rows + 3) / 4));
-    hipLaunchKernelGGL(lmhead_combine_kernel, dim3(cgrid), dim3(256), 0, s, (const float*)part, count, dst_pos, V, alg,
-                       temperature > 0.f ? 1 : 0, round_conf_bf16, conf, x0);
+    hipLaunchKernelGGL(lmhead_combine_kernel, dim3(cgrid), dim3(256), 0, s, (const float*)part, count, dst_pos, max_rows, V,
+                       alg, temperature > 0.f ? 1 : 0, round_conf_bf16, conf, x0);
     CODA_CHECK_LAUNCH("lmhead_combine");
     return CODA_OK;
 }

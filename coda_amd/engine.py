@@ -295,31 +295,79 @@ class HipEngine:
     def set_mask_id(self, mask_id: int):
         self._mask_id = int(mask_id)
 
+    # ------------------------------------------------------------------ logits buffers (reserved BEFORE the denoise loop)
+    def reserve(self, B: int, L: int, cap: int, filtered: bool, full_logits: bool = False):
+        """Called once per generate, before the first denoise step: every buffer the loop will need exists afterwards, so
+        no step allocates (a first allocation of 2.5 GB in the middle of a generation can fail after the forward buffers
+        are resident).  ``cap``: largest candidate-row bound of the run; ``filtered``: top-p / top-k are active (their rows
+        always go through materialised logits); ``full_logits``: a logits hook wants the shifted [B, L, V] tensor."""
+        self._ensure(B, L)
+        if filtered or cap >= self.materialise_min_rows or full_logits:
+            self._reserve_chunk(min(cap, self.logits_chunk_rows))
+        if full_logits and getattr(self, "_full_shape", None) != (B, L):
+            self._full_hidden = torch.empty(B * L, self.H, device=self.device, dtype=torch.bfloat16)
+            self._full_logits = torch.empty(B * L, self.V, device=self.device, dtype=torch.bfloat16)
+            pos = torch.arange(L, device=self.device, dtype=torch.int32)
+            self._shift_rows = (torch.arange(B, device=self.device, dtype=torch.int32)[:, None] * L
+                                + (pos - 1).clamp_min(0)[None, :]).reshape(-1).contiguous()
+            self._full_shape = (B, L)
+
+    def _reserve_chunk(self, rows: int):
+        """One [rows, V] bf16 logits buffer + its compacted hidden rows, shared by every materialised route (long candidate
+        lists, top-p / top-k, hooks).  If the device cannot hold the preferred chunk the chunk is halved (more, shorter
+        launches; same results) down to 1024 rows."""
+        if getattr(self, "_mat_rows", 0) >= rows:
+            return
+        self._mat_hidden = self._mat_logits = None
+        while True:
+            try:
+                self._mat_hidden = torch.empty(rows, self.H, device=self.device, dtype=torch.bfloat16)
+                self._mat_logits = torch.empty(rows, self.V, device=self.device, dtype=torch.bfloat16)
+                break
+            except torch.OutOfMemoryError:
+                self._mat_hidden = self._mat_logits = None
+                if rows <= 1024:
+                    raise
+                rows = max(1024, rows // 2)
+                self.logits_chunk_rows = min(self.logits_chunk_rows, rows)
+        self._mat_rows = rows
+        if getattr(self, "_mat_counts", None) is None:
+            self._mat_counts = torch.zeros(4096, device=self.device, dtype=torch.int32)
+
     @_on_device
-    def lmhead_confidence(self, max_rows: int, alg: int, temperature: float, noise, seed: int, round_conf: bool):
+    def lmhead_confidence(self, max_rows: int, alg: int, temperature: float, noise, seed: int, round_conf: bool,
+                          top_p=None, top_k=None):
+        """lm_head + sample_tokens over the candidate rows (modeling_coda.py:411, generation_utils.py:61-100): the fused
+        kernel for short unfiltered lists, the chunked materialised route otherwise."""
         self._dev(noise, "token noise", torch.float32)
-        if max_rows >= self.materialise_min_rows:
-            return self._lmhead_materialised(max_rows, alg, temperature, noise, seed, round_conf)
+        if top_p is not None or top_k is not None or max_rows >= self.materialise_min_rows:
+            return self._lmhead_materialised(max_rows, alg, temperature, noise, seed, round_conf, top_p, top_k)
         _lib.call("coda_lmhead_confidence", _ptr(self.hn), self.H, _ptr(self.src_rows), _ptr(self.dst_pos), _ptr(self.count),
                   max_rows, _ptr(self.lm_head), self.H, self.V, self.H, alg, float(temperature), _ptr(noise), seed,
                   int(round_conf), _ptr(self.conf), _ptr(self.x0), _ptr(self.lm_ws), self._stream())
 
-    def _lmhead_materialised(self, max_rows: int, alg: int, temperature: float, noise, seed: int, round_conf: bool):
-        """Same result as the fused kernel by the route that measures faster from ~2k candidate rows on (17 % at 4k-65k rows,
-        `tools/lmhead_unfused_bench.py`): the rows are compacted, projected by the four-wave GEMM engine into a bf16
-        logits buffer and reduced by the confidence kernel - chunk by chunk, so the buffer stays at ``logits_chunk_rows``
-        x V (2.5 GB) however long the candidate list is.  The chunks' row counts are derived on the device."""
-        chunk = min(max_rows, self.logits_chunk_rows)
+    def _chunks(self, max_rows: int):
+        """(chunk rows, number of chunks, per-chunk device counts) for a candidate list walked through the reserved logits
+        buffer; the chunks' row counts are derived on the device (no host read)."""
+        want = min(max_rows, self.logits_chunk_rows)
+        if getattr(self, "_mat_rows", 0) < want:
+            self._reserve_chunk(want)                  # direct engine use (tests, tools): reserve() was not called
+        chunk = min(want, self._mat_rows)
         n_chunks = (max_rows + chunk - 1) // chunk
-        if getattr(self, "_mat_rows", 0) < chunk:
-            self._mat_hidden = torch.empty(chunk, self.H, device=self.device, dtype=torch.bfloat16)
-            self._mat_logits = torch.empty(chunk, self.V, device=self.device, dtype=torch.bfloat16)
-            self._mat_rows = chunk
-        if getattr(self, "_mat_counts", None) is None or self._mat_counts.numel() < n_chunks:
-            self._mat_counts = torch.zeros(max(n_chunks, 16), device=self.device, dtype=torch.int32)
-        s, hid, out = self._stream(), self._mat_hidden, self._mat_logits
+        if n_chunks > self._mat_counts.numel():
+            raise _lib.CodaHipError(f"{max_rows} candidate rows need {n_chunks} chunks of {chunk} rows: raise logits_chunk_rows")
         if n_chunks > 1:
-            _lib.call("coda_chunk_counts", _ptr(self.count), chunk, n_chunks, _ptr(self._mat_counts), s)
+            _lib.call("coda_chunk_counts", _ptr(self.count), chunk, n_chunks, _ptr(self._mat_counts), self._stream())
+        return chunk, n_chunks
+
+    def _lmhead_materialised(self, max_rows: int, alg: int, temperature: float, noise, seed: int, round_conf: bool,
+                             top_p=None, top_k=None):
+        """Same result as the fused kernel by the route that measures faster from ~2k candidate rows on (17 % at 4k-65k rows,
+        `tools/lmhead_unfused_bench.py`), and the only route for top-p / top-k: the rows are compacted, projected by the
+        four-wave GEMM engine into a bf16 logits buffer and reduced by the confidence kernel - chunk by chunk, so the
+        buffer stays at ``logits_chunk_rows`` x V (2.5 GB) however long the candidate list is."""
+        chunk, n_chunks = self._chunks(max_rows)
+        s, hid, out = self._stream(), self._mat_hidden, self._mat_logits
         for c in range(n_chunks):
             rows = min(chunk, max_rows - c * chunk)
             cnt = _ptr(self.count) if n_chunks == 1 else _ptr(self._mat_counts) + 4 * c
@@ -328,25 +376,63 @@ class HipEngine:
             _lib.call("coda_gemm_bf16_counted", _ptr(hid), hid.stride(0), cnt, _ptr(self.lm_head), self.lm_head.stride(0),
                       _ptr(out), out.stride(0), rows, self.V, self.H, s)
             _lib.call("coda_confidence_from_logits", _ptr(out), out.stride(0), 1, rows, self.V, cnt,
-                      _ptr(self.dst_pos) + 4 * c * chunk, alg, float(temperature), 0.0, 0,
+                      _ptr(self.dst_pos) + 4 * c * chunk, alg, float(temperature),
+                      float(top_p) if top_p is not None else 0.0, int(top_k) if top_k is not None else 0,
                       None if noise is None else _ptr(noise) + 4 * c * chunk * self.V, seed, int(round_conf),
                       _ptr(self.conf), _ptr(self.x0), s)
 
     @_on_device
     def candidate_logits(self, max_rows: int) -> torch.Tensor:
-        """Materialises bf16 logits [max_rows, V] of the candidate rows (top-p / top-k path)."""
-        if getattr(self, "_cand_shape", None) != max_rows:
-            # resident for the generation: compacted hidden rows and their logits (top-p / top-k read them several times)
-            self._cand_hidden = torch.empty(max_rows, self.H, device=self.device, dtype=torch.bfloat16)
-            self._cand_logits = torch.empty(max_rows, self.V, device=self.device, dtype=torch.bfloat16)
-            self._cand_shape = max_rows
-        hc, out = self._cand_hidden, self._cand_logits
+        """bf16 logits [max_rows, V] of the candidate rows in the reserved buffer (tests and tools; the denoise loop walks
+        the same buffer chunk by chunk in _lmhead_materialised).  max_rows must fit one chunk."""
+        self._reserve_chunk(max_rows)
+        hc, out = self._mat_hidden, self._mat_logits
         _lib.call("coda_gather_rows", _ptr(self.hn), self.hn.stride(0), _ptr(self.src_rows), _ptr(self.count), max_rows,
                   _ptr(hc), hc.stride(0), self.H, self._stream())
         # only count[0] rows are projected (the candidate set shrinks every step; max_rows bounds the launch)
         _lib.call("coda_gemm_bf16_counted", _ptr(hc), hc.stride(0), _ptr(self.count), _ptr(self.lm_head), self.lm_head.stride(0),
                   _ptr(out), out.stride(0), max_rows, self.V, self.H, self._stream())
-        return out
+        return out[:max_rows]
+
+    @_on_device
+    def shifted_logits(self, B: int, L: int) -> torch.Tensor:
+        """What a logits hook sees (generation_utils.py:456-460): bf16 [B, L, V] with logits[:, p] = lm_head(hidden[:, p-1])
+        (position 0 keeps its own), from the hidden states of the last forward_hidden() over ALL rows.  The shift is a row
+        gather of the hidden states in front of the GEMM - no [B, L, V] `torch.cat` copy; the buffer is engine-owned and
+        reused every step (reserve(full_logits=True))."""
+        if getattr(self, "_full_shape", None) != (B, L):
+            self.reserve(B, L, B * L, False, full_logits=True)
+        T = B * L
+        _lib.call("coda_gather_rows", _ptr(self.hn), self.hn.stride(0), _ptr(self._shift_rows), None, T, _ptr(self._full_hidden),
+                  self.H, self.H, self._stream())
+        self._gemm("lm_head_full", self._full_hidden, self.lm_head, self._full_logits, _lib.EPI_PLAIN)
+        return self._full_logits.view(B, L, self.V)
+
+    @_on_device
+    def confidence_from_full_logits(self, logits: torch.Tensor, max_rows: int, alg: int, temperature: float, top_p, top_k,
+                                    noise, seed: int, round_conf: bool):
+        """sample_tokens over `logits[mask_index]` (generation_utils.py:462) where ``logits`` is the [B, L, V] tensor a
+        logits hook returned: the candidate rows are compacted by coda_gather_rows on dst_pos (bf16) chunk by chunk into
+        the reserved buffer - no torch index_select copy of the whole candidate set."""
+        B, L, V = logits.shape
+        flat = logits.reshape(B * L, V)
+        if flat.dtype != torch.bfloat16 or flat.stride(1) != 1 or flat.stride(0) % 8 or flat.data_ptr() % 16:
+            # a hook that changed the dtype / layout: the confidence kernel takes fp32 or bf16 rows, compacted by torch
+            rows = flat.index_select(0, self.dst_pos[:max_rows].long())
+            rows = rows if rows.dtype in (torch.bfloat16, torch.float32) else rows.float()
+            return self.confidence_from_logits(rows.contiguous(), alg, temperature, top_p, top_k, noise, seed, round_conf)
+        chunk, n_chunks = self._chunks(max_rows)
+        s, out = self._stream(), self._mat_logits
+        for c in range(n_chunks):
+            rows = min(chunk, max_rows - c * chunk)
+            cnt = _ptr(self.count) if n_chunks == 1 else _ptr(self._mat_counts) + 4 * c
+            _lib.call("coda_gather_rows", _ptr(flat), flat.stride(0), _ptr(self.dst_pos) + 4 * c * chunk, cnt, rows, _ptr(out),
+                      out.stride(0), V, s)
+            _lib.call("coda_confidence_from_logits", _ptr(out), out.stride(0), 1, rows, V, cnt,
+                      _ptr(self.dst_pos) + 4 * c * chunk, alg, float(temperature),
+                      float(top_p) if top_p is not None else 0.0, int(top_k) if top_k is not None else 0,
+                      None if noise is None else _ptr(noise) + 4 * c * chunk * V, seed, int(round_conf),
+                      _ptr(self.conf), _ptr(self.x0), s)
 
     @_on_device
     def confidence_from_logits(self, logits: torch.Tensor, alg: int, temperature: float, top_p, top_k, noise, seed: int,

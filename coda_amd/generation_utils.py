@@ -97,6 +97,72 @@ class DeviceNoise:
         return None
 
 
+class LazyLogits:
+    """What a TOKENS hook receives as its ``logits`` argument when no logits hook forces them to exist.  The reference
+    hands every tokens hook the step's shifted [B, L, V] logits (generation_utils.py:541); most hooks only look at the
+    step index and ``x``.  This object stands for that tensor and materialises it - one full forward of the state the
+    step STARTED from + the shifted lm-head, into the engine's own buffer - the first time the hook touches it (an
+    attribute, an index, an arithmetic operator, or passing it to a torch function); a hook that never does leaves the
+    fused, logits-free route untouched.  The materialised tensor lives in an engine buffer that the next step reuses:
+    clone it to keep it."""
+
+    def __init__(self, engine, x_before):
+        object.__setattr__(self, "_engine", engine)
+        object.__setattr__(self, "_x", x_before)
+        object.__setattr__(self, "_t", None)
+
+    def materialize(self) -> torch.Tensor:
+        if self._t is None:
+            B, L = self._x.shape
+            self._engine.forward_hidden(self._x)
+            object.__setattr__(self, "_t", self._engine.shifted_logits(B, L))
+        return self._t
+
+    @property
+    def materialized(self) -> bool:
+        return self._t is not None
+
+    def __getattr__(self, name):
+        return getattr(self.materialize(), name)
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+    def __len__(self):
+        return self._x.shape[0]
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __repr__(self):
+        return f"LazyLogits(materialized={self.materialized}, batch={tuple(self._x.shape)})"
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        def unwrap(a):
+            if isinstance(a, LazyLogits):
+                return a.materialize()
+            if isinstance(a, (list, tuple)):
+                return type(a)(unwrap(v) for v in a)
+            return a
+        return func(*unwrap(args), **{k: unwrap(v) for k, v in (kwargs or {}).items()})
+
+
+def _lazy_binary(name):
+    def op(self, other):
+        other = other.materialize() if isinstance(other, LazyLogits) else other
+        return getattr(self.materialize(), name)(other)
+    op.__name__ = name
+    return op
+
+
+for _n in ("add", "sub", "mul", "truediv", "floordiv", "pow", "matmul", "radd", "rsub", "rmul", "rtruediv",
+           "lt", "le", "gt", "ge", "eq", "ne"):
+    setattr(LazyLogits, f"__{_n}__", _lazy_binary(f"__{_n}__"))
+LazyLogits.__neg__ = lambda self: -self.materialize()
+LazyLogits.__hash__ = object.__hash__
+
+
 @dataclass
 class _Call:
     """Per-call options that are not generation_config fields (kept off the model object: two generate calls must
@@ -245,6 +311,17 @@ class DLMGenerationMixin:
             generation_config.pad_token_id = int(first)
             logger.warning(f"Setting `pad_token_id` to `eos_token_id`:{generation_config.pad_token_id} for open-end generation.")
 
+    @staticmethod
+    def _hooked_tokens(x, eng, shape):
+        """What a tokens hook returned goes straight into kernels: same checks as the ids at the door."""
+        if not isinstance(x, torch.Tensor) or tuple(x.shape) != tuple(shape):
+            raise ValueError(f"generation_tokens_hook_func must return a tensor of shape {tuple(shape)}")
+        if x.device != eng.device:
+            raise _lib.CodaHipError(f"generation_tokens_hook_func returned a tensor on {x.device}, the model is on {eng.device}")
+        if x.dtype.is_floating_point or x.dtype == torch.bool:
+            raise _lib.CodaHipError(f"generation_tokens_hook_func must return an integer tensor, got {x.dtype}")
+        return x.to(torch.int64).contiguous()
+
     # ------------------------------------------------------------------------------ the denoise loop
     def _sample(self, input_ids, attention_mask, generation_config, tokens_hook, logits_hook, call=None):
         """Device-resident restatement of the reference loop (generation_utils.py:412-552).
@@ -272,13 +349,20 @@ class DLMGenerationMixin:
         round_conf = gc.round_conf_to in ("bf16", torch.bfloat16, "bfloat16")
         top_p = gc.top_p if (gc.top_p is not None and gc.top_p < 1) else None
         top_k = gc.top_k
-        materialise_all = logits_hook is not None or tokens_hook is not None
-        fused = not materialise_all and top_p is None and top_k is None
+        # hooks (generation_utils.py:453,460,541).  A LOGITS hook sees and may rewrite the shifted [B, L, V] logits: they
+        # are materialised every step (reference semantics), into one engine-owned buffer, and the candidate rows are
+        # compacted from what the hook returned.  A TOKENS hook alone keeps the fused route: it is handed a lazily
+        # materialised logits object that costs nothing unless the hook actually reads it.
+        materialise_all = logits_hook is not None
+        filtered = top_p is not None or top_k is not None
         alg_id = _lib.ALG_IDS.get(alg, 0)                # confidence_threshold scores like maskgit_plus: p[x0]
         a_temp = float(alg_temp) if alg_temp else 0.0
 
         if tokens_hook is not None:
-            x = tokens_hook(None, x, None)
+            x = self._hooked_tokens(tokens_hook(None, x, None), eng, (B, L))
+        whole_row = call.prompt_has_mask or tokens_hook is not None     # a tokens hook may re-mask any position
+        cap_max = B * ((L if whole_row else G) if n_blocks == 1 else bl)
+        eng.reserve(B, L, cap_max, filtered, full_logits=materialise_all)
         steps = gc.steps
         if alg == "confidence_threshold":
             # serving/dream/model/generation_utils.py:416-422: one sequence, a fixed quota per step plus whatever
@@ -298,16 +382,12 @@ class DLMGenerationMixin:
             blk, j = divmod(min(i, gc.steps - 1), steps_b)
             if n_blocks == 1:
                 # reference mode: every masked position of the row is a candidate (prompt included if it holds masks)
-                lo, hi = (0 if call.prompt_has_mask or tokens_hook is not None else P), L
+                lo, hi = (0 if whole_row else P), L
             else:
                 lo, hi = P + blk * bl, P + (blk + 1) * bl
             cap = B * (hi - lo)
             last = j == steps_b - 1
 
-            # the lm-head reads the hidden state at p-1 for every candidate p in [lo, hi) (:457,462): positions [lo-1, hi-1)
-            s_lo = max(lo - 1, 0)
-            hn = eng.forward_hidden(x, need=None if materialise_all else (s_lo, max(hi - 1, s_lo + 1)))
-            eng.build_candidates(x, lo, hi)
             u = picked = None
             if alg == "origin":
                 p_transfer = 1.0 if last else ratios[j]
@@ -316,20 +396,19 @@ class DLMGenerationMixin:
             tok_noise = noise.token_noise(i, cap, eng.V, picked) if temperature > 0 else None
             seed = noise.step_seed(i)
             logits = None
-            if fused:
-                eng.lmhead_confidence(cap, alg_id, temperature, tok_noise, seed, round_conf)
-            elif not materialise_all:
-                rows = eng.candidate_logits(cap)
-                eng.confidence_from_logits(rows, alg_id, temperature, top_p, top_k, tok_noise, seed, round_conf)
+            if materialise_all:
+                eng.forward_hidden(x)                                          # every row: the hook sees [B, L, V]
+                logits = logits_hook(i, x, eng.shifted_logits(B, L))          # logits[:, p] predicts token p (:457)
+                eng.build_candidates(x, lo, hi)
+                eng.confidence_from_full_logits(logits, cap, alg_id, temperature, top_p, top_k, tok_noise, seed, round_conf)
             else:
-                full = eng.logits(x)                                          # [B, L, V]
-                logits = torch.cat([full[:, :1], full[:, :-1]], dim=1)        # logits[p] predicts token p
-                if logits_hook is not None:
-                    logits = logits_hook(i, x, logits)
-                rows = logits.reshape(B * L, -1).index_select(0, eng.dst_pos[:cap].long())
-                if rows.dtype not in (torch.bfloat16, torch.float32):
-                    rows = rows.float()
-                eng.confidence_from_logits(rows.contiguous(), alg_id, temperature, top_p, top_k, tok_noise, seed, round_conf)
+                # the lm-head reads the hidden state at p-1 for every candidate p in [lo, hi) (:457,462): positions [lo-1, hi-1)
+                s_lo = max(lo - 1, 0)
+                eng.forward_hidden(x, need=(s_lo, max(hi - 1, s_lo + 1)))
+                eng.build_candidates(x, lo, hi)
+                eng.lmhead_confidence(cap, alg_id, temperature, tok_noise, seed, round_conf, top_p, top_k)
+                if tokens_hook is not None:
+                    logits = LazyLogits(eng, x.clone())
 
             if call.debug_trace is not None:
                 call.debug_trace.append(dict(step=i, conf=eng.conf.clone(), x0=eng.x0.clone(), count=eng.count.clone(),
@@ -350,7 +429,7 @@ class DLMGenerationMixin:
                     call.debug_trace[-1]["k"] = eng.k_out.clone()
 
             if tokens_hook is not None:
-                x = tokens_hook(i, x, logits)
+                x = self._hooked_tokens(tokens_hook(i, x, logits), eng, (B, L))
             if histories is not None:
                 histories.append(x.clone())
 

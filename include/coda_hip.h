@@ -138,6 +138,12 @@ int coda_flash_attn_noncausal(const void* qkv, long long ld_qkv, void* out, long
 int coda_flash_attn_noncausal_ex(const void* qkv, long long ld_qkv, void* out, long long ld_out, int B, int L, int n_q,
                                  int n_kv, float scale, int pair_mode, int qsplit, void* stream);
 
+/* Diagnostic: 1 if `logits / temperature` (generation_utils.py:71) runs on the verified three-operation quotient for bf16
+ * logits at this temperature, 0 if the kernels take the IEEE division (coda_amd/csrc/coda_common.h::coda_div_by: the fast
+ * form is licensed per temperature by an exhaustive host check over all bf16 inputs; fp32 logits always divide).  Either
+ * way the quotient is the correctly rounded one; host-only, touches no GPU. */
+int coda_temperature_fast_division(float temperature);
+
 /* Candidate list for one denoise step.  Replaces `mask_index = x == mask_token_id`,
  * the shift `cat(logits[:, :1], logits[:, :-1])` and the boolean gather `logits[mask_index]`
  * (generation_utils.py:455-462) without touching logits: for every masked position p of row b

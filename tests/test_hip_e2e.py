@@ -320,6 +320,64 @@ def test_hooks_and_history_contract(small):
         m.diffusion_generate(ids, max_length=8, steps=4, alg="entropy", mask_token_id=d.mask_id)
 
 
+def test_hooks_fast_paths(small):
+    """SURVEY 8(f)4 / generation_utils.py:453,460,541.  (i) a TOKENS hook alone keeps the fused, logits-free route: it is
+    handed a LazyLogits that stays unmaterialised unless read, and the run equals the hook-free run; (ii) a tokens hook that
+    does read it gets the step's shifted logits - the same tensor a logits hook sees; (iii) the logits hook's tensor is
+    `cat(logits[:, :1], logits[:, :-1])` of model(x) (built without that copy) and lives in one engine buffer."""
+    from coda_amd.generation_utils import LazyLogits
+    d, sd, m = small
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(0, d.pad_id, (3, 16), generator=g).to(DEV)
+    kw = dict(max_new_tokens=32, steps=8, alg="entropy", mask_token_id=d.mask_id, block_length=8)
+    plain = m.diffusion_generate(ids, **kw)
+    lazies = []
+
+    def tok_hook(step, x, logits):
+        if step is not None:
+            lazies.append(logits)
+        return x
+    hooked = m.diffusion_generate(ids, generation_tokens_hook_func=tok_hook, **kw)
+    assert torch.equal(plain, hooked)
+    assert len(lazies) == 8 and all(isinstance(z, LazyLogits) and not z.materialized for z in lazies)
+
+    seen_tok, seen_log, states = [], [], []
+
+    def reading_hook(step, x, logits):
+        if step is not None:
+            assert tuple(logits.shape) == (3, 48, d.vocab) and logits.dtype == BF        # attribute access materialises
+            seen_tok.append((logits[:, 5].clone(), torch.softmax(logits.float(), -1).amax(-1), (logits * 2)[0, 0, :4].clone()))
+        return x
+
+    def log_hook(step, x, logits):
+        states.append(x.clone())
+        seen_log.append(logits.clone())
+        return logits
+    a = m.diffusion_generate(ids, generation_tokens_hook_func=reading_hook, **kw)
+    b = m.diffusion_generate(ids, generation_logits_hook_func=log_hook, **kw)
+    assert torch.equal(a, plain)
+    assert (b != plain).sum().item() <= 1          # materialised vs fused route: same logits, confidences to 1e-6 (near-ties)
+    if torch.equal(b, plain):
+        for (col, pmax, twice), full in zip(seen_tok, seen_log):
+            assert torch.equal(col, full[:, 5]) and torch.equal(twice, (full * 2)[0, 0, :4])
+            assert torch.equal(pmax, torch.softmax(full.float(), -1).amax(-1))
+    for x, full in zip(states, seen_log):
+        ref, _ = m(x)
+        assert torch.equal(full, torch.cat([ref[:, :1], ref[:, :-1]], dim=1))
+    # a hook that rewrites the logits steers the sampler: force token 7 everywhere
+    def force7(step, x, logits):
+        out = torch.full_like(logits, -30.0)
+        out[..., 7] = 30.0
+        return out
+    c = m.diffusion_generate(ids, generation_logits_hook_func=force7, **kw)
+    assert (c[:, 16:] == 7).all() and torch.equal(c[:, :16], ids)
+    # ... also when it returns another dtype (fp32): compacted by torch, same result
+    c32 = m.diffusion_generate(ids, generation_logits_hook_func=lambda s_, x, l: force7(s_, x, l).float(), **kw)
+    assert torch.equal(c32, c)
+    with pytest.raises(Exception):
+        m.diffusion_generate(ids, generation_tokens_hook_func=lambda s_, x, l: x.cpu(), **kw)
+
+
 class Replay:
     """Feeds noise recorded from an oracle run (CPU tensors) to the HIP path."""
 

@@ -620,6 +620,32 @@ def test_lmhead_confidence_independent_of_the_launch_bound(temperature):
         assert torch.equal(x4, x1) and torch.equal(c4, c1), alg_id
 
 
+def test_lmhead_confidence_count_beyond_the_launch_bound_is_clamped():
+    """A device-side candidate count LARGER than max_rows (a caller's bookkeeping error) must not write past what max_rows
+    sized: the partial records (here: guarded by a canary behind the workspace) and conf / x0 beyond the first max_rows
+    candidates stay untouched; the first max_rows candidates come out as in a well-formed call."""
+    g = torch.Generator().manual_seed(31)
+    H, V, n_rows, cap = 128, 5000, 600, 256
+    hidden = torch.randn(n_rows, H, generator=g).to(BF).to(DEV)
+    W = (torch.randn(V, H, generator=g) * 0.25).to(BF).to(DEV)
+    src = torch.arange(n_rows, dtype=torch.int32).to(DEV)
+    dst = torch.arange(n_rows, dtype=torch.int32).to(DEV)
+    good = torch.tensor([cap], dtype=torch.int32).to(DEV)
+    bad = torch.tensor([n_rows], dtype=torch.int32).to(DEV)
+    ws_bytes = _lib.load().coda_lmhead_workspace_bytes(cap, V)
+    for alg_id in (0, 2):
+        c_ok, x_ok = _lmhead(hidden, W, src, dst, good, cap, alg_id, T_total=n_rows)
+        conf = torch.full((n_rows,), float("nan"), device=DEV)
+        x0 = torch.full((n_rows,), -1, device=DEV, dtype=torch.int64)
+        ws = torch.full((ws_bytes + 4096,), 0x5A, device=DEV, dtype=torch.uint8)
+        _lib.call("coda_lmhead_confidence", _p(hidden), hidden.stride(0), _p(src), _p(dst), _p(bad), cap, _p(W), W.stride(0), V, H,
+                  alg_id, 0.0, None, 0, 0, _p(conf), _p(x0), _p(ws), _s())
+        torch.cuda.synchronize()
+        assert torch.equal(conf[:cap], c_ok[:cap]) and torch.equal(x0[:cap], x_ok[:cap])
+        assert torch.isnan(conf[cap:]).all() and (x0[cap:] == -1).all()
+        assert (ws[ws_bytes:] == 0x5A).all()
+
+
 def test_in_kernel_noise_top_hash_value_does_not_win():
     """Regression: (seed 77, row key 565, token 148599) hashes to the largest value.  With 24 hash bits + 0.5 that became
     u = 1.0 in fp32, -log(u) = 0 and a race key of +inf: the token won whatever its logit.  u now stays below 1, the key is

@@ -305,3 +305,20 @@ def test_hash_uniform_stays_strictly_inside_the_unit_interval():
     from parity import hash_uniform_host
     u = hash_uniform_host(0x1234567890, torch.arange(64)[:, None], torch.arange(4096)[None, :])
     assert float(u.min()) >= 2.0 ** -24 and float(u.max()) <= 1.0 - 2.0 ** -24
+
+
+def test_fast_division_is_licensed_per_temperature_by_the_library():
+    """coda_div_by's three-operation quotient is used only for temperatures at which the library has verified it, on the
+    host, against the IEEE quotient for EVERY bf16 input of its fast-path domain (csrc/abi_misc.hip); anything else - and
+    every fp32-logits call - takes the true division (the ABI accepts any temperature).  Host-only call."""
+    import numpy as np
+    from coda_amd import _lib
+    lib = _lib.load()
+    for t in (0.1, 0.7, 0.5, 0.8, 1.3, 0.6, 1.0):          # the configurations' temperatures run on the fast form
+        assert lib.coda_temperature_fast_division(t) == 1, t
+    for t in (0.0, -0.5, 1e-6, 5e4, float("nan")):         # outside its stated range: division
+        assert lib.coda_temperature_fast_division(t) == 0, t
+    rng = np.random.default_rng(5)
+    flags = [lib.coda_temperature_fast_division(float(np.float32(t))) for t in rng.uniform(0.02, 4.0, 300)]
+    assert set(flags) <= {0, 1}                              # every verdict is a verified one, whichever way it falls
+    print(f"fast division licensed at {sum(flags)} of {len(flags)} random temperatures")

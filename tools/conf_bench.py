@@ -8,6 +8,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from coda_amd import _lib  # noqa: E402
 
+if os.environ.get("ALT_LIB"):                 # another build of the library (tools/alt/, not tracked): A/B across builds
+    _lib.LIB_PATH = os.path.abspath(os.environ["ALT_LIB"])
 _lib.load()
 N, V = int(os.environ.get("ROWS", "8192")), 151936
 torch.manual_seed(0)
