@@ -25,6 +25,8 @@ SIGNATURES = {
     "coda_gemm_bf16": (_i, [_p, _ll, _p, _p, _ll, _p, _ll, _p, _ll, _i, _i, _i, _i, _p]),
     "coda_gemm_bf16_ex": (_i, [_p, _ll, _p, _p, _ll, _p, _ll, _p, _ll, _i, _i, _i, _i, _i, _i, _p]),
     "coda_gemm_bf16_splitk": (_i, [_p, _ll, _p, _ll, _p, _ll, _p, _ll, _i, _i, _i, _i, _i, _p, _ll, _p]),
+    "coda_gemm_bf16_splitk_norm": (_i, [_p, _ll, _p, _ll, _p, _ll, _p, _ll, _i, _i, _i, _i, _p, _ll, _p, _p, _ll, _f, _p]),
+    "coda_qkv_proj_rope_splitk": (_i, [_p, _ll, _p, _ll, _p, _ll, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _ll, _p]),
     "coda_qknorm_rope": (_i, [_p, _ll, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "coda_qkv_proj_rope": (_i, [_p, _ll, _p, _ll, _p, _ll, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "coda_qkv_proj_rope_w4": (_i, [_p, _ll, _p, _ll, _p, _ll, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),

@@ -46,6 +46,15 @@ __device__ __forceinline__ void round_bf16_pair(float& a, float& b) {
     b = bf16_hi(pk);
 }
 
+// 8 bf16 (one 16-byte piece) -> 8 floats
+__device__ __forceinline__ void unpack8(const u32x4_t v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(v[i] << 16);
+        f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+
 // Counter-based uniform in (0, 1): a pure function of (seed, row key, index).  All sampling noise that is not injected
 // by the caller comes from here (token noise: row key = flat position of the candidate, index = vocabulary id;
 // selection / origin noise: index = 0xFFFFFFFF / 0xFFFFFFFE), so a run is reproducible from its seed alone and no

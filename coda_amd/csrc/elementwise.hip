@@ -95,13 +95,6 @@ extern "C" int coda_scatter_rows(const void* src, long long ld_src, const int* r
 
 // ------------------------------------------------------------------ RMSNorm
 // modeling_coda.py:36-41: y = w * bf16(x_f32 * rsqrt(mean(x_f32^2) + eps)), product rounded to bf16.
-__device__ __forceinline__ void unpack8(const u32x4_t v, float (&f)[8]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        f[2 * i] = __uint_as_float(v[i] << 16);
-        f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
-    }
-}
 
 template <int MAXC>   // MAXC: chunks (of 512 elements) kept in registers per lane
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const char* __restrict__ x, long long ldx_b, const u32x4_t* __restrict__ w,

@@ -1381,6 +1381,207 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
     }
 }
 
+// ---- split-K epilogues fused with the row-wise op that FOLLOWS the projection in the decoder (B = 1: ~230 launches of
+// 4-35 us per denoise step; each of these removes one).  Both mirror the thread -> element mapping and the summation order
+// of the kernels they replace (splitk_epilogue_kernel, then rmsnorm_kernel / qknorm_rope_kernel), so the results are
+// bit-identical to the two-launch sequence.
+//
+// o_proj / down_proj + residual (modeling_coda.py:247,253), then the NEXT RMSNorm (:36-41: post-attention norm, the next
+// layer's input norm, or the final norm): one wave per token row, a lane owns 16-byte pieces c = lane + 64 i of the row.
+template <int MAXC>
+__global__ __launch_bounds__(64) void splitk_residual_rmsnorm_kernel(const float* __restrict__ part, long long slab_floats, int ksplit,
+                                                                     int M, int N, char* __restrict__ C, long long ldc_bytes,
+                                                                     const char* __restrict__ R, long long ldr_bytes,
+                                                                     const u32x4_t* __restrict__ nw, char* __restrict__ normed,
+                                                                     long long ldn_bytes, float eps) {
+    const int lane = threadIdx.x, row = blockIdx.x;
+    if (row >= M) return;
+    const int chunks = N / 8;
+    u32x4_t keep[MAXC];
+    float ss = 0.f;
+    // partial sums: slabs in ascending order per element (the order of splitk_epilogue_kernel), but with the loads of four
+    // slabs x MAXC pieces in flight per lane - a lone wave per row has only its own loads to hide the latency with
+    f32x4_t lo[MAXC], hi[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) lo[i] = hi[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const float* prow = part + (size_t)row * N;
+    for (int s0 = 0; s0 < ksplit; s0 += 4) {
+        f32x4_t a[4][MAXC], b[4][MAXC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = lane + 64 * i;
+                const bool on = s0 + u < ksplit && c < chunks;
+                const float* p = prow + (size_t)(on ? s0 + u : s0) * slab_floats + (on ? c : lane) * 8;
+                a[u][i] = *(const f32x4_t*)p;
+                b[u][i] = *(const f32x4_t*)(p + 4);
+                if (!on) a[u][i] = b[u][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (s0 + u < ksplit) {
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    lo[i] += a[u][i];
+                    hi[i] += b[u][i];
+                }
+            }
+    }
+    u32x4_t res[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        res[i] = *(const u32x4_t*)(R + (size_t)row * ldr_bytes + (size_t)(c < chunks ? c : lane) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < chunks) {
+            const u32x4_t r = res[i];
+            u32x4_t v = {pack_bf16x2(lo[i][0], lo[i][1]), pack_bf16x2(lo[i][2], lo[i][3]), pack_bf16x2(hi[i][0], hi[i][1]),
+                         pack_bf16x2(hi[i][2], hi[i][3])};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = pack_bf16x2(bf16_lo(v[j]) + bf16_lo(r[j]), bf16_hi(v[j]) + bf16_hi(r[j]));
+            *(u32x4_t*)(C + (size_t)row * ldc_bytes + (size_t)c * 16) = v;
+            keep[i] = v;
+            float f[8];
+            unpack8(v, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+        }
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(ss / (float)N + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < chunks) {
+            float f[8], g[8];
+            unpack8(keep[i], f);
+            unpack8(nw[c], g);
+            u32x4_t o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] = pack_bf16x2(g[2 * j] * round_bf16(f[2 * j] * inv), g[2 * j + 1] * round_bf16(f[2 * j + 1] * inv));
+            *(u32x4_t*)(normed + (size_t)row * ldn_bytes + (size_t)c * 16) = o;
+        }
+    }
+}
+
+// q/k/v projection (modeling_coda.py:123-125), then q_norm / k_norm + rotary (:128-148, modeling_utils.py:70-101) on the q
+// and k heads; v heads are only rounded.  16 lanes per (token, head) row of 128 features, as qknorm_rope_kernel.
+__global__ __launch_bounds__(256) void splitk_qknorm_rope_kernel(const float* __restrict__ part, long long slab_floats, int ksplit,
+                                                                 int T, int N, char* __restrict__ qkv, long long ld_b,
+                                                                 const u32x4_t* __restrict__ qw, const u32x4_t* __restrict__ kw,
+                                                                 const u32x4_t* __restrict__ cs, const u32x4_t* __restrict__ sn,
+                                                                 int L, int n_q, int n_qk, float eps) {
+    const int sub = threadIdx.x & 15;
+    const int n_heads = N / 128;                            // q, k and v heads
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long long total = (long long)T * n_heads;
+    const bool live = row < total;
+    const long long rr = live ? row : total - 1;            // keep all lanes in the shuffles
+    const int t = (int)(rr / n_heads), h = (int)(rr % n_heads);
+    f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < ksplit; ++s) {
+        const float* p = part + (size_t)s * slab_floats + (size_t)t * N + h * 128 + sub * 8;
+        lo += *(const f32x4_t*)p;
+        hi += *(const f32x4_t*)(p + 4);
+    }
+    const u32x4_t v = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+    u32x4_t* out = (u32x4_t*)(qkv + (size_t)t * ld_b + (size_t)h * 256) + sub;
+    float f[8];
+    unpack8(v, f);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float inv = 1.0f / sqrtf(ss * (1.0f / 128.0f) + eps);
+    float w[8], c[8], sv[8], n[8], other[8];
+    const int hh = min(h, n_qk - 1);
+    unpack8((hh < n_q ? qw : kw)[sub], w);
+    const int pos = t % L;
+    unpack8(cs[(size_t)pos * 16 + sub], c);
+    unpack8(sn[(size_t)pos * 16 + sub], sv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) n[j] = round_bf16(w[j] * round_bf16(f[j] * inv));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) other[j] = __shfl_xor(n[j], 8, 64);
+    const float sign = sub < 8 ? -1.0f : 1.0f;              // rotate_half: first half takes -x2, second half x1
+    u32x4_t o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a0 = round_bf16(n[2 * i] * c[2 * i]) + round_bf16(sign * other[2 * i] * sv[2 * i]);
+        const float a1 = round_bf16(n[2 * i + 1] * c[2 * i + 1]) + round_bf16(sign * other[2 * i + 1] * sv[2 * i + 1]);
+        o[i] = pack_bf16x2(a0, a1);
+    }
+    if (live) *out = h < n_qk ? o : v;
+}
+
+// shared front half of the split-K entry points: argument checks + the partial-tile GEMM into the workspace
+static int splitk_partials(const void* X, long long ldx, const void* W, long long ldw, int M, int N, int K, int ksplit,
+                           void* workspace, long long workspace_bytes, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0 || ksplit < 2 || N % 32 != 0 || K % ksplit != 0 || (K / ksplit) % BK != 0) return CODA_ERR_SHAPE;
+    if (!X || !W || !workspace) return CODA_ERR_ARG;
+    if ((long long)ksplit * M * N * 4 > workspace_bytes) return CODA_ERR_SHAPE;
+    if (((uintptr_t)X | (uintptr_t)W | (uintptr_t)workspace) & 15 || (ldx * 2) % 16 || (ldw * 2) % 16) return CODA_ERR_ALIGN;
+    GemmArgs a{};
+    a.X = (const char*)X; a.ldx_bytes = ldx * 2; a.x_rows = nullptr;
+    a.W = (const char*)W; a.ldw_bytes = ldw * 2;
+    a.C = (char*)workspace; a.ldc_bytes = (long long)N * 4;
+    a.M = M; a.N = N; a.K = K;
+    a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
+    a.wide = 0;
+    a.ksplit = ksplit; a.slab_bytes = (long long)M * N * 4;
+    return launch<EPI_F32>(a, s);
+}
+
+extern "C" int coda_gemm_bf16_splitk_norm(const void* X, long long ldx, const void* W, long long ldw, void* C, long long ldc,
+                                          const void* R, long long ldr, int M, int N, int K, int ksplit, void* workspace,
+                                          long long workspace_bytes, const void* norm_weight, void* normed, long long ld_normed,
+                                          float eps, void* stream) {
+    if (!C || !R || !norm_weight || !normed) return CODA_ERR_ARG;
+    if (N % 8 || N > 8 * 64 * 8) return CODA_ERR_SHAPE;                  // a lane keeps at most 8 pieces of the row in registers
+    if (((uintptr_t)C | (uintptr_t)R | (uintptr_t)norm_weight | (uintptr_t)normed) & 15 || (ldc * 2) % 16 || (ldr * 2) % 16 ||
+        (ld_normed * 2) % 16)
+        return CODA_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = splitk_partials(X, ldx, W, ldw, M, N, K, ksplit, workspace, workspace_bytes, s);
+    if (rc != CODA_OK) return rc;
+    const float* part = (const float*)workspace;
+    const long long slab = (long long)M * N;
+    if (N <= 4 * 64 * 8)
+        hipLaunchKernelGGL(splitk_residual_rmsnorm_kernel<4>, dim3(M), dim3(64), 0, s, part, slab, ksplit, M, N, (char*)C, ldc * 2,
+                           (const char*)R, ldr * 2, (const u32x4_t*)norm_weight, (char*)normed, ld_normed * 2, eps);
+    else
+        hipLaunchKernelGGL(splitk_residual_rmsnorm_kernel<8>, dim3(M), dim3(64), 0, s, part, slab, ksplit, M, N, (char*)C, ldc * 2,
+                           (const char*)R, ldr * 2, (const u32x4_t*)norm_weight, (char*)normed, ld_normed * 2, eps);
+    CODA_CHECK_LAUNCH("splitk_residual_rmsnorm");
+    return CODA_OK;
+}
+
+extern "C" int coda_qkv_proj_rope_splitk(const void* X, long long ldx, const void* W, long long ldw, void* qkv, long long ld,
+                                         const void* q_weight, const void* k_weight, const void* cos, const void* sin, int T,
+                                         int L, int n_q, int n_kv, int K, float eps, int ksplit, void* workspace,
+                                         long long workspace_bytes, void* stream) {
+    const int N = (n_q + 2 * n_kv) * 128;
+    if (T <= 0 || L <= 0 || T % L || n_q <= 0 || n_kv <= 0 || ld < N) return CODA_ERR_SHAPE;
+    if (!qkv || !q_weight || !k_weight || !cos || !sin) return CODA_ERR_ARG;
+    if (((uintptr_t)qkv | (uintptr_t)q_weight | (uintptr_t)k_weight | (uintptr_t)cos | (uintptr_t)sin) & 15 || (ld * 2) % 16)
+        return CODA_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = splitk_partials(X, ldx, W, ldw, T, N, K, ksplit, workspace, workspace_bytes, s);
+    if (rc != CODA_OK) return rc;
+    const long long rows = (long long)T * (N / 128);
+    hipLaunchKernelGGL(splitk_qknorm_rope_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, (const float*)workspace,
+                       (long long)T * N, ksplit, T, N, (char*)qkv, ld * 2, (const u32x4_t*)q_weight, (const u32x4_t*)k_weight,
+                       (const u32x4_t*)cos, (const u32x4_t*)sin, L, n_q, n_q + n_kv, eps);
+    CODA_CHECK_LAUNCH("splitk_qknorm_rope");
+    return CODA_OK;
+}
+
 extern "C" int coda_gemm_bf16_splitk(const void* X, long long ldx, const void* W, long long ldw, void* C, long long ldc,
                                      const void* R, long long ldr, int M, int N, int K, int epilogue, int ksplit,
                                      void* workspace, long long workspace_bytes, void* stream) {

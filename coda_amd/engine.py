@@ -120,6 +120,7 @@ class HipEngine:
         self._rope = {}
         self.timer = None          # optional KernelTimer (bench.py)
         self.prune_last_layer = True   # forward_hidden(need=...): last layer's per-token tail on the consumed rows only
+        self.fuse_splitk_epilogues = True  # small T: split-K reduce kernels also do the row-wise op that follows (A/B knob)
         self.materialise_min_rows = 2048   # launch bound from which lmhead_confidence takes the materialised route
         self.logits_chunk_rows = 8192      # ... and its logits buffer's rows
 
@@ -232,8 +233,10 @@ class HipEngine:
         prune = self.prune_last_layer and need is not None and 0 <= need[0] < need[1] <= L and 5 * (need[1] - need[0]) <= 4 * L
         _lib.call("coda_embed_gather", _ptr(ids), _ptr(self.embed), _ptr(self.h), T, self.V, self.H, s)
         scale = 1.0 / math.sqrt(self.d)
+        normed = False         # self.a already holds this layer's input norm (written by the previous layer's fused down_proj)
         for li, lw in enumerate(self.lw):
-            _lib.call("coda_rmsnorm", _ptr(self.h), self.H, _ptr(lw["n_in"]), _ptr(self.a), self.H, T, self.H, self.eps, s)
+            if not normed:
+                _lib.call("coda_rmsnorm", _ptr(self.h), self.H, _ptr(lw["n_in"]), _ptr(self.a), self.H, T, self.H, self.eps, s)
             # the fused epilogue lives on the 256x256 persistent engine: below ~2048 tokens its 256-token tiles leave most
             # of the chip idle (T = 384: 32 workgroups), and the deep-ring 128x128 engine + the standalone norm/rotary kernel win
             if self.fuse_qk and T >= 2048:
@@ -245,19 +248,60 @@ class HipEngine:
                 if t is not None:
                     t.end("qkv")
             else:
-                self._gemm("qkv", self.a, lw["wqkv"], self.qkv, _lib.EPI_PLAIN)
-                _lib.call("coda_qknorm_rope", _ptr(self.qkv), self.qkv_dim, _ptr(lw["qn"]), _ptr(lw["kn"]), _ptr(cos),
-                          _ptr(sin), T, L, self.n_q, self.n_kv, self.eps, s)
+                ks = self._ksplit(T, self.qkv_dim, self.H) if self.fuse_splitk_epilogues else 1
+                if ks > 1:        # small T: split-K partials, reduced by ONE kernel that also does q/k-norm + rotary
+                    _lib.call("coda_qkv_proj_rope_splitk", _ptr(self.a), self.H, _ptr(lw["wqkv"]), self.H, _ptr(self.qkv),
+                              self.qkv_dim, _ptr(lw["qn"]), _ptr(lw["kn"]), _ptr(cos), _ptr(sin), T, L, self.n_q, self.n_kv, self.H,
+                              self.eps, ks, _ptr(self._splitk_workspace()), SPLITK_WS_BYTES, s)
+                else:
+                    self._gemm("qkv", self.a, lw["wqkv"], self.qkv, _lib.EPI_PLAIN)
+                    _lib.call("coda_qknorm_rope", _ptr(self.qkv), self.qkv_dim, _ptr(lw["qn"]), _ptr(lw["kn"]), _ptr(cos),
+                              _ptr(sin), T, L, self.n_q, self.n_kv, self.eps, s)
             _lib.call("coda_flash_attn_noncausal", _ptr(self.qkv), self.qkv_dim, _ptr(self.ao), self.n_q * self.d, B, L,
                       self.n_q, self.n_kv, scale, s)
             if prune and li == self.layers - 1:
                 return self._compact_tail(lw, B, L, need[0], need[1])
-            self._gemm("o_proj", self.ao, lw["wo"], self.h, _lib.EPI_RESIDUAL, R=self.h)
-            _lib.call("coda_rmsnorm", _ptr(self.h), self.H, _ptr(lw["n_post"]), _ptr(self.a), self.H, T, self.H, self.eps, s)
+            self._proj_residual_norm("o_proj", self.ao, lw["wo"], self.h, lw["n_post"], self.a, T)
             self._gemm("gate_up", self.a, lw["wgu"], self.mlp, _lib.EPI_SWIGLU)
-            self._gemm("down", self.mlp, lw["wd"], self.h, _lib.EPI_RESIDUAL, R=self.h)
+            last = li == self.layers - 1
+            normed = self._proj_residual_norm("down", self.mlp, lw["wd"], self.h, self.final_norm if last else self.lw[li + 1]["n_in"],
+                                              self.hn if last else self.a, T, norm_optional=True)
+            if last and normed:
+                return self.hn
         _lib.call("coda_rmsnorm", _ptr(self.h), self.H, _ptr(self.final_norm), _ptr(self.hn), self.H, T, self.H, self.eps, s)
         return self.hn
+
+    def _ksplit(self, M: int, N: int, K: int) -> int:
+        ks = splitk_factor(M, N, K) if N % 32 == 0 else 1
+        return ks if ks > 1 and ks * M * N * 4 <= SPLITK_WS_BYTES else 1
+
+    def _splitk_workspace(self) -> torch.Tensor:
+        if getattr(self, "_splitk_ws", None) is None:
+            self._splitk_ws = torch.empty(SPLITK_WS_BYTES, device=self.device, dtype=torch.uint8)
+        return self._splitk_ws
+
+    def _proj_residual_norm(self, name, X, W, h, norm_w, out, M, split_like=None, norm_optional=False) -> bool:
+        """h[:M] += X W^T (o_proj / down_proj + residual, modeling_coda.py:247,253), then ``out = RMSNorm(h) * norm_w`` - the
+        norm that follows it in the decoder.  With split-K (small M) the partial sums are reduced, added to the residual AND
+        normalised by one kernel (coda_gemm_bf16_splitk_norm: same bits, one launch fewer).  ``norm_optional``: when there is
+        no split-K the norm is left to the caller (returns False) - the next layer's loop head or the final norm do it."""
+        N, K = W.shape
+        ks = self._ksplit(M if split_like is None else split_like, N, K)
+        if self.fuse_splitk_epilogues and ks > 1 and ks * M * N * 4 <= SPLITK_WS_BYTES and N <= 4096:
+            t = self.timer
+            if t is not None:
+                t.begin(name, 2.0 * M * N * K)
+            _lib.call("coda_gemm_bf16_splitk_norm", _ptr(X), X.stride(0), _ptr(W), W.stride(0), _ptr(h), h.stride(0), _ptr(h),
+                      h.stride(0), M, N, K, ks, _ptr(self._splitk_workspace()), SPLITK_WS_BYTES, _ptr(norm_w), _ptr(out),
+                      out.stride(0), self.eps, self._stream())
+            if t is not None:
+                t.end(name)
+            return True
+        self._gemm(name, X, W, h, _lib.EPI_RESIDUAL, R=h, M=M, split_like=split_like)
+        if norm_optional:
+            return False
+        _lib.call("coda_rmsnorm", _ptr(h), h.stride(0), _ptr(norm_w), _ptr(out), out.stride(0), M, self.H, self.eps, self._stream())
+        return True
 
     def _compact_tail(self, lw, B: int, L: int, lo: int, hi: int) -> torch.Tensor:
         """Last layer after attention, on the rows b*L + [lo, hi) only (see forward_hidden)."""
@@ -266,11 +310,9 @@ class HipEngine:
         _lib.call("coda_gather_rows", _ptr(self.ao), D, _ptr(rows), None, R, _ptr(self.ao_c), D, D, s)
         _lib.call("coda_gather_rows", _ptr(self.h), self.H, _ptr(rows), None, R, _ptr(self.h_c), self.H, self.H, s)
         T = B * L                                # K is summed in the ranges the full forward uses at T rows: bit-identical rows
-        self._gemm("o_proj_tail", self.ao_c, lw["wo"], self.h_c, _lib.EPI_RESIDUAL, R=self.h_c, split_like=T)
-        _lib.call("coda_rmsnorm", _ptr(self.h_c), self.H, _ptr(lw["n_post"]), _ptr(self.a_c), self.H, R, self.H, self.eps, s)
+        self._proj_residual_norm("o_proj_tail", self.ao_c, lw["wo"], self.h_c, lw["n_post"], self.a_c, R, split_like=T)
         self._gemm("gate_up_tail", self.a_c, lw["wgu"], self.mlp_c, _lib.EPI_SWIGLU, split_like=T)
-        self._gemm("down_tail", self.mlp_c, lw["wd"], self.h_c, _lib.EPI_RESIDUAL, R=self.h_c, split_like=T)
-        _lib.call("coda_rmsnorm", _ptr(self.h_c), self.H, _ptr(self.final_norm), _ptr(self.hn_c), self.H, R, self.H, self.eps, s)
+        self._proj_residual_norm("down_tail", self.mlp_c, lw["wd"], self.h_c, self.final_norm, self.hn_c, R, split_like=T)
         _lib.call("coda_scatter_rows", _ptr(self.hn_c), self.H, _ptr(rows), R, _ptr(self.hn), self.H, B * L, self.H, s)
         return self.hn
 

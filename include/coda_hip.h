@@ -81,6 +81,22 @@ int coda_gemm_bf16_splitk(const void* X, long long ldx, const void* W, long long
                           const void* R, long long ldr, int M, int N, int K, int epilogue, int ksplit, void* workspace,
                           long long workspace_bytes, void* stream);
 
+/* coda_gemm_bf16_splitk(CODA_EPI_RESIDUAL) followed by coda_rmsnorm on its output, in ONE reduce launch: C = bf16(bf16(X W^T)
+ * + R) (modeling_coda.py:247,253) and normed = CoDARMSNorm(C) (:36-41: the post-attention norm, the next layer's input norm
+ * or the final norm).  Same bits as the two calls (same summation orders).  B = 1 serving shape: one launch fewer per
+ * projection.  N % 8 == 0, N <= 4096; other constraints as coda_gemm_bf16_splitk; ksplit >= 2. */
+int coda_gemm_bf16_splitk_norm(const void* X, long long ldx, const void* W, long long ldw, void* C, long long ldc,
+                               const void* R, long long ldr, int M, int N, int K, int ksplit, void* workspace,
+                               long long workspace_bytes, const void* norm_weight, void* normed, long long ld_normed, float eps,
+                               void* stream);
+
+/* coda_gemm_bf16_splitk(CODA_EPI_PLAIN) of the fused q|k|v projection followed by coda_qknorm_rope, in ONE reduce launch
+ * (modeling_coda.py:123-148, modeling_utils.py:70-101).  W bf16 [(n_q + 2 n_kv) * 128, K] in natural row order.  Same bits as
+ * the two calls.  ksplit >= 2, K % ksplit == 0, (K / ksplit) % 64 == 0; workspace ksplit * T * N * 4 bytes. */
+int coda_qkv_proj_rope_splitk(const void* X, long long ldx, const void* W, long long ldw, void* qkv, long long ld,
+                              const void* q_weight, const void* k_weight, const void* cos, const void* sin, int T, int L, int n_q,
+                              int n_kv, int K, float eps, int ksplit, void* workspace, long long workspace_bytes, void* stream);
+
 /* q_norm / k_norm + rotary embedding, in place on the fused QKV activation.
  * Replaces modeling_coda.py:128-148 and modeling_utils.py:70-101.
  * qkv bf16 [T, (n_q + 2 n_kv) * 128]: q heads, then k heads, then v heads (v untouched).

@@ -149,6 +149,60 @@ def test_gemm_splitk_exact_integer(M, N, K, ks, epi):
     assert lib.coda_gemm_bf16_splitk(_p(X), K, _p(W), K, _p(C), cols, _p(R), 0 if R is None else N, M, N, K, code, ks, _p(ws), 16, _s()) == -1
 
 
+@pytest.mark.parametrize("M,N,K,ks", [(384, 2048, 2048, 8), (384, 2048, 6144, 8), (32, 2048, 6144, 8), (77, 256, 512, 2), (5, 4096, 1024, 4)])
+def test_splitk_residual_norm_equals_two_calls(M, N, K, ks):
+    """coda_gemm_bf16_splitk_norm (B = 1 serving shape: o_proj / down_proj + residual + the RMSNorm that follows, one reduce
+    launch): bit-identical to coda_gemm_bf16_splitk(RESIDUAL) + coda_rmsnorm on random-normal data, out of place and in
+    place on the residual stream as the decoder calls it."""
+    g = torch.Generator().manual_seed(71)
+    X = (torch.randn(M, K, generator=g) * 0.5).to(BF).to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(BF).to(DEV)
+    R = torch.randn(M, N, generator=g).to(BF).to(DEV)
+    nw = (1 + 0.2 * torch.randn(N, generator=g)).to(BF).to(DEV)
+    ws = torch.empty(ks * M * N * 4 + 64, device=DEV, dtype=torch.uint8)
+    C0 = torch.full((M, N), float("nan"), device=DEV, dtype=BF)
+    _lib.call("coda_gemm_bf16_splitk", _p(X), K, _p(W), K, _p(C0), N, _p(R), N, M, N, K, _lib.EPI_RESIDUAL, ks, _p(ws), ws.numel(), _s())
+    A0 = torch.full((M, N), float("nan"), device=DEV, dtype=BF)
+    _lib.call("coda_rmsnorm", _p(C0), N, _p(nw), _p(A0), N, M, N, 1e-6, _s())
+    C1 = torch.full((M, N), float("nan"), device=DEV, dtype=BF)
+    A1 = torch.full((M, N), float("nan"), device=DEV, dtype=BF)
+    _lib.call("coda_gemm_bf16_splitk_norm", _p(X), K, _p(W), K, _p(C1), N, _p(R), N, M, N, K, ks, _p(ws), ws.numel(), _p(nw), _p(A1),
+              N, 1e-6, _s())
+    torch.cuda.synchronize()
+    assert torch.equal(C1, C0) and torch.equal(A1, A0)
+    Rc, A2 = R.clone(), torch.full((M, N), float("nan"), device=DEV, dtype=BF)
+    _lib.call("coda_gemm_bf16_splitk_norm", _p(X), K, _p(W), K, _p(Rc), N, _p(Rc), N, M, N, K, ks, _p(ws), ws.numel(), _p(nw), _p(A2),
+              N, 1e-6, _s())
+    torch.cuda.synchronize()
+    assert torch.equal(Rc, C0) and torch.equal(A2, A0)
+    lib = _lib.load()
+    assert lib.coda_gemm_bf16_splitk_norm(_p(X), K, _p(W), K, _p(C1), N, _p(R), N, M, N, K, 1, _p(ws), ws.numel(), _p(nw), _p(A1), N, 1e-6, _s()) == -1
+    assert lib.coda_gemm_bf16_splitk_norm(_p(X), K, _p(W), K, _p(C1), N, _p(R), N, M, N, K, ks, _p(ws), 16, _p(nw), _p(A1), N, 1e-6, _s()) == -1
+
+
+@pytest.mark.parametrize("B,L,n_q,n_kv,K,ks", [(1, 384, 16, 8, 2048, 4), (2, 50, 4, 2, 512, 2), (1, 33, 2, 1, 256, 2)])
+def test_splitk_qkv_rope_equals_two_calls(B, L, n_q, n_kv, K, ks):
+    """coda_qkv_proj_rope_splitk: split-K q|k|v projection whose reduce kernel also applies q_norm / k_norm + rotary -
+    bit-identical to coda_gemm_bf16_splitk(PLAIN) + coda_qknorm_rope."""
+    g = torch.Generator().manual_seed(72)
+    T, N = B * L, (n_q + 2 * n_kv) * 128
+    X = (torch.randn(T, K, generator=g) * 0.5).to(BF).to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(BF).to(DEV)
+    qw = (1 + 0.2 * torch.randn(128, generator=g)).to(BF).to(DEV)
+    kw = (1 + 0.2 * torch.randn(128, generator=g)).to(BF).to(DEV)
+    cos, sin = ref_cpu.rope_tables(L, 128, 1e6, BF)
+    cos, sin = cos.contiguous().to(DEV), sin.contiguous().to(DEV)
+    ws = torch.empty(ks * T * N * 4, device=DEV, dtype=torch.uint8)
+    Q0 = torch.full((T, N), float("nan"), device=DEV, dtype=BF)
+    _lib.call("coda_gemm_bf16_splitk", _p(X), K, _p(W), K, _p(Q0), N, None, 0, T, N, K, _lib.EPI_PLAIN, ks, _p(ws), ws.numel(), _s())
+    _lib.call("coda_qknorm_rope", _p(Q0), N, _p(qw), _p(kw), _p(cos), _p(sin), T, L, n_q, n_kv, 1e-6, _s())
+    Q1 = torch.full((T, N), float("nan"), device=DEV, dtype=BF)
+    _lib.call("coda_qkv_proj_rope_splitk", _p(X), K, _p(W), K, _p(Q1), N, _p(qw), _p(kw), _p(cos), _p(sin), T, L, n_q, n_kv, K, 1e-6,
+              ks, _p(ws), ws.numel(), _s())
+    torch.cuda.synchronize()
+    assert torch.equal(Q1, Q0)
+
+
 def test_gemm_identity_asymmetric():
     K = 128
     X = torch.eye(K).to(BF)
