@@ -48,3 +48,29 @@ def full_model():
     with torch.no_grad():
         m.lm_head.weight.mul_(8.0)
     return cfg, m
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _progress_heartbeat():
+    """The full-size parity tests spend minutes inside the CPU oracle without printing; the GPU box takes a command that
+    writes nothing for three minutes to be hung.  A daemon thread notes the elapsed time in gpurun_out/heartbeat.log once a
+    minute while the session runs (only where a GPU is present: the CPU suite has no such test)."""
+    import threading
+    import time
+    import torch
+    if not torch.cuda.is_available():
+        yield
+        return
+    stop = threading.Event()
+    path = os.path.join(ROOT, "gpurun_out", "heartbeat.log")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    t0 = time.time()
+
+    def beat():
+        while not stop.wait(60.0):
+            with open(path, "a") as f:
+                f.write(f"pytest session alive, {time.time() - t0:.0f} s\n")
+    th = threading.Thread(target=beat, daemon=True)
+    th.start()
+    yield
+    stop.set()
