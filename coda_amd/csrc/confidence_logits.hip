@@ -746,6 +746,18 @@ __global__ __launch_bounds__(HT) void confidence_hist_kernel(ConfArgs a) {
             run += c;
         }
         kk = (unsigned int)hreduce<int>(cand, red_i, tid, imaxl);
+        if (sampled) {
+            // top_k_logits keeps every entry EQUAL to the k-th largest (`logits < kth` is what it removes), and it compares
+            // the quotients: a lower original value whose quotient rounds to the same bf16 is kept too (T > 1 makes such
+            // collisions common)
+            const float xk = xform(value_of_key16(kk));
+            int low = (int)kk;
+            for (int e = e0; e < e1; ++e) {
+                const unsigned int k = list[e] >> 16;
+                if (k < kk && xform(value_of_key16(k)) == xk) low = min(low, (int)k);
+            }
+            kk = (unsigned int)hreduce<int>(low, red_i, tid, iminl);
+        }
         // top_k_logits runs on the top-p filtered row: if top-p kept fewer than top_k tokens the k-th largest is a removed
         // entry (finfo.min) and top-k removes nothing more
         if (use_p && kk < kp) kk = 0u;

@@ -941,6 +941,52 @@ def test_confidence_top_p_tie_cut_negative_threshold(scale, top_p):
     assert (conf_e.double() - ent_ref).abs().max() < 2e-3
 
 
+def test_confidence_counting_kernel_equals_generic_kernel():
+    """bf16 logits with top-p / top-k go through the counting kernel (one pass over exact 16-bit keys + list work); the
+    generic radix kernel stays for fp32 logits, unaligned rows and as the fallback for rows the 16-bit counters cannot hold.
+    Same rows through both (the generic one is forced by a 2-byte misaligned copy): tokens identical, confidences to fp32
+    summation order - flat, peaked and tie-heavy rows, rows with banned (-inf) entries, and the two fallback triggers (a
+    value repeated >= 32 768 times; more distinct values than the list holds) mixed into the same launch."""
+    g = torch.Generator().manual_seed(41)
+    V = 151936
+    rows = [torch.randn(4, V, generator=g) * 0.9, torch.randn(4, V, generator=g) * 7.0,
+            (torch.randn(4, V, generator=g) * 2.0 * 4).round() / 4]                       # flat, peaked, ties on a 0.25 grid
+    banned = torch.randn(2, V, generator=g) * 3.0
+    banned[:, ::3] = -float("inf")
+    rep = torch.randn(2, V, generator=g) * 2.0
+    rep[:, :40000] = -30.0                                                                # one value 40 000 times: counter wraps
+    wide = torch.randn(2, V, generator=g) * torch.exp(torch.randn(2, V, generator=g) * 4.0)   # > 6144 distinct bf16 values
+    logits = torch.cat(rows + [banned, rep, wide]).to(BF)
+    N = logits.shape[0]
+    assert (wide.to(BF)[0].unique().numel() > 6144) and N == 18
+    al = logits.to(DEV).contiguous()
+    pad = torch.zeros(N, V + 8, dtype=BF, device=DEV)
+    pad[:, 1:V + 1] = al
+    mis = pad[:, 1:V + 1]                                                                  # same values, rows start 2 bytes off 16
+    assert al.data_ptr() % 16 == 0 and mis.data_ptr() % 16 == 2 and mis.stride(0) % 8 == 0
+
+    def run(t, alg, T, top_p, top_k):
+        conf = torch.full((N,), float("nan"), device=DEV)
+        x0 = torch.full((N,), -7, device=DEV, dtype=torch.int64)
+        _lib.call("coda_confidence_from_logits", _p(t), t.stride(0), 1, N, V, None, None, alg, T, top_p, top_k, None, 4242, 0,
+                  _p(conf), _p(x0), _s())
+        torch.cuda.synchronize()
+        return conf.cpu(), x0.cpu()
+    for T, top_p, top_k in ((0.0, 0.9, 0), (0.0, 0.0, 50), (0.7, 0.9, 0), (0.1, 0.9, 40), (1.3, 0.0, 20), (0.0, 0.5, 3)):
+        for alg in (0, 1, 2):
+            ca, xa = run(al, alg, T, top_p, top_k)
+            cm, xm = run(mis, alg, T, top_p, top_k)
+            assert torch.equal(xa, xm), (T, top_p, top_k, alg, (xa != xm).nonzero().flatten().tolist())
+            assert (xa >= 0).all() and (xa < V).all()
+            err = (ca - cm).abs()
+            assert torch.isfinite(ca).all() and float(err.max()) <= 2e-5 * max(1.0, float(cm.abs().max())), (T, top_p, top_k, alg, err)
+    # and against the oracle on the greedy settings (fp32 softmax of the same bf16 values; top-p boundary band as above)
+    for top_p, top_k in ((0.9, None), (None, 50)):
+        c_ref, x_ref = ref_cpu.sample_tokens(logits[:12].float(), 0.0, top_p, top_k, neg_entropy=True)
+        conf, x0 = _conf_logits(logits[:12], 2, 0.0, top_p or 0.0, top_k or 0)
+        assert torch.equal(x0, x_ref) and (conf - c_ref).abs().max() < 2e-3, (top_p, top_k)
+
+
 @pytest.mark.parametrize("scale", [1.0, 12.0])
 def test_in_kernel_token_noise_race_matches_host_hash(scale):
     """temperature > 0 with noise == NULL: x0 = argmax(l / T - log(-log u)), u = coda_hash_uniform(seed, row key, v).  The
