@@ -1413,7 +1413,10 @@ __global__ __launch_bounds__(64) void splitk_residual_rmsnorm_kernel(const float
             for (int i = 0; i < MAXC; ++i) {
                 const int c = lane + 64 * i;
                 const bool on = s0 + u < ksplit && c < chunks;
-                const float* p = prow + (size_t)(on ? s0 + u : s0) * slab_floats + (on ? c : lane) * 8;
+                // lanes / slabs that are off re-read piece 0 of slab s0 of THIS row: always inside the row (rows shorter than
+                // 512 features leave lanes without a piece; an address derived from the lane would leave the row - and, on the
+                // last row of a buffer, the allocation)
+                const float* p = prow + (size_t)(on ? s0 + u : s0) * slab_floats + (on ? c : 0) * 8;
                 a[u][i] = *(const f32x4_t*)p;
                 b[u][i] = *(const f32x4_t*)(p + 4);
                 if (!on) a[u][i] = b[u][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -1432,7 +1435,7 @@ __global__ __launch_bounds__(64) void splitk_residual_rmsnorm_kernel(const float
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
-        res[i] = *(const u32x4_t*)(R + (size_t)row * ldr_bytes + (size_t)(c < chunks ? c : lane) * 16);
+        res[i] = *(const u32x4_t*)(R + (size_t)row * ldr_bytes + (size_t)(c < chunks ? c : 0) * 16);
     }
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
