@@ -4,6 +4,7 @@
 #include "gemm_tile128.h"
 #include "gemm_tile256.h"
 #include "gemm_tile256x128.h"
+#include "gemm_tile192.h"
 #include "coda_abi_internal.h"
 
 using namespace tile128;
@@ -240,6 +241,130 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     epilogue_tile<EPI, 4>(a, acc, m0 + wm * 64, n0 + wn * 64, lane, m0 + BM <= a.M && n0 + BN <= a.N);
 }
 
+
+// Two-block tail of a wave tile whose feature width is not a multiple of 64 (gemm_tile192.h: 96 = 64 + 32 features):
+// the same rounding points as epilogue_wave, 8-byte pieces only.
+template <int EPI, int MT, bool FULL>
+__device__ __forceinline__ void epilogue_tail2(const GemmArgs& a, const f32x4_t (&acc)[2][MT], int mrow0, int ncol0, int lane) {
+    const int tok = lane & 15, fq = (lane >> 4) * 4;
+    const int mf = mrow0 + tok;
+    const size_t rs = (size_t)16 * a.ldc_bytes;
+    if constexpr (EPI == EPI_SWIGLU) {
+        const int nb = ncol0 / 2 + fq;             // block 0 = 16 gate rows, block 1 = their 16 up rows
+        if (!FULL && nb >= a.N / 2) return;
+        char* c = a.C + (size_t)mf * a.ldc_bytes + (size_t)nb * 2;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (!FULL && mf + mt * 16 >= a.M) continue;
+            const unsigned g01 = pack_bf16x2(acc[0][mt][0], acc[0][mt][1]), g23 = pack_bf16x2(acc[0][mt][2], acc[0][mt][3]);
+            const unsigned u01 = pack_bf16x2(acc[1][mt][0], acc[1][mt][1]), u23 = pack_bf16x2(acc[1][mt][2], acc[1][mt][3]);
+            float s0 = silu_f32(bf16_lo(g01)), s1 = silu_f32(bf16_hi(g01));
+            float s2 = silu_f32(bf16_lo(g23)), s3 = silu_f32(bf16_hi(g23));
+            round_bf16_pair(s0, s1);
+            round_bf16_pair(s2, s3);
+            *(u32x2_t*)(c + mt * rs) =
+                (u32x2_t){pack_bf16x2(s0 * bf16_lo(u01), s1 * bf16_hi(u01)), pack_bf16x2(s2 * bf16_lo(u23), s3 * bf16_hi(u23))};
+        }
+    } else if constexpr (EPI == EPI_F32) {
+        const int nb = ncol0 + fq;
+        char* c = a.C + (size_t)mf * a.ldc_bytes + (size_t)nb * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (!FULL && mf + mt * 16 >= a.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                if (!FULL && nb + nt * 16 >= a.N) continue;
+                *(f32x4_t*)(c + mt * rs + nt * 64) = acc[nt][mt];
+            }
+        }
+    } else {
+        const int nb = ncol0 + fq;
+        char* c = a.C + (size_t)mf * a.ldc_bytes + (size_t)nb * 2;
+        u32x2_t rv[MT][2];
+        if constexpr (EPI == EPI_RESIDUAL) {       // all residual loads before the first store (C may alias R)
+            const char* r = a.R + (size_t)mf * a.ldr_bytes + (size_t)nb * 2;
+            const size_t rrs = (size_t)16 * a.ldr_bytes;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    rv[mt][nt] = (u32x2_t){0u, 0u};
+                    if (FULL || (mf + mt * 16 < a.M && nb + nt * 16 < a.N)) rv[mt][nt] = *(const u32x2_t*)(r + mt * rrs + nt * 32);
+                }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (!FULL && mf + mt * 16 >= a.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                if (!FULL && nb + nt * 16 >= a.N) continue;
+                unsigned v0 = pack_bf16x2(acc[nt][mt][0], acc[nt][mt][1]);
+                unsigned v1 = pack_bf16x2(acc[nt][mt][2], acc[nt][mt][3]);
+                if constexpr (EPI == EPI_RESIDUAL) {
+                    v0 = pack_bf16x2(bf16_lo(v0) + bf16_lo(rv[mt][nt][0]), bf16_hi(v0) + bf16_hi(rv[mt][nt][0]));
+                    v1 = pack_bf16x2(bf16_lo(v1) + bf16_lo(rv[mt][nt][1]), bf16_hi(v1) + bf16_hi(rv[mt][nt][1]));
+                }
+                *(u32x2_t*)(c + mt * rs + nt * 32) = (u32x2_t){v0, v1};
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// (32*MT)x192 engine (gemm_tile192.h): few token rows, one tile per CU, three ring stages.  No row gather, no device
+// row count, no split-K.
+template <int EPI, int MT, int STAGES, bool TALL>
+__global__ __launch_bounds__(256, 2) void gemm192_bf16_kernel(GemmArgs a) {
+    using T = tile192::Tile<MT, STAGES, TALL>;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = TALL ? wave : wave >> 1, wn = TALL ? 0 : wave & 1;
+
+    // consecutive ids walk the row tiles of one feature panel, an XCD's chunk of ids covers whole panels:
+    // every weight panel is fetched from HBM by one XCD only, the (small) activation matrix lives in every L2
+    const int ntile = a.tiles_m * a.tiles_n;
+    const int id = xcd_remap(blockIdx.x, ntile);
+    const int tm = id % a.tiles_m, tn = id / a.tiles_m;
+    const int m0 = tm * T::BM, n0 = tn * T::BN;
+
+    typename T::Src f;
+    const int ch = T::dma_chunk(lane) * 16;
+#pragma unroll
+    for (int i = 0; i < T::XI; ++i) f.x[i] = a.X + (size_t)min(m0 + T::dma_row(i, wave, lane), a.M - 1) * a.ldx_bytes + ch;
+#pragma unroll
+    for (int i = 0; i < T::WI; ++i) f.w[i] = a.W + (size_t)min(n0 + T::dma_row(i, wave, lane), a.N - 1) * a.ldw_bytes + ch;
+
+    f32x4_t acc[4][MT], tail[2][MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) tail[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+
+    T::mainloop(f, a.K, lds, wave, lane, acc, tail);
+
+    const bool full = m0 + T::BM <= a.M && n0 + T::BN <= a.N;
+    const int mrow0 = m0 + wm * 16 * MT, ncol0 = n0 + wn * 96;
+    epilogue_tile<EPI, MT>(a, acc, mrow0, ncol0, lane, full);
+    if (full) epilogue_tail2<EPI, MT, true>(a, tail, mrow0, ncol0 + 64, lane);
+    else epilogue_tail2<EPI, MT, false>(a, tail, mrow0, ncol0 + 64, lane);
+}
+
+template <int EPI, int MT, int STAGES = 3, bool TALL = false>
+static int launch192(GemmArgs a, hipStream_t s) {
+    using T = tile192::Tile<MT, STAGES, TALL>;
+    if (coda_ensure_dyn_lds((const void*)gemm192_bf16_kernel<EPI, MT, STAGES, TALL>, T::LDS_BYTES) != CODA_OK) return CODA_ERR_LAUNCH;
+    a.tiles_m = (a.M + T::BM - 1) / T::BM;
+    a.tiles_n = (a.N + T::BN - 1) / T::BN;
+    hipLaunchKernelGGL((gemm192_bf16_kernel<EPI, MT, STAGES, TALL>), dim3(a.tiles_m * a.tiles_n), dim3(256), T::LDS_BYTES, s, a);
+    CODA_CHECK_LAUNCH("gemm192_bf16");
+    return CODA_OK;
+}
+template <int EPI> static int launch96x192(GemmArgs a, hipStream_t s) { return launch192<EPI, 3>(a, s); }
+template <int EPI> static int launch128x192(GemmArgs a, hipStream_t s) { return launch192<EPI, 4>(a, s); }
+template <int EPI> static int launch192x96(GemmArgs a, hipStream_t s) { return launch192<EPI, 3, 3, true>(a, s); }
 
 // ---------------------------------------------------------------------------------------------
 // 256x256 engine (gemm_tile256.h): same epilogues, no row gather.
@@ -1189,6 +1314,14 @@ static int pick_engine(const GemmArgs& a, int forced) {
     if (a.N >= 256 && t192 >= 200 && fill(t192) >= 0.85) return 6;
     if (a.m_count) return a.N >= 256 && t256 >= 200 ? 3 : 0;     // counted launches: engines that read m_count
     if (t128 >= 200 && fill(t128) >= 0.85) return 4;
+    // a few hundred rows x many features (B = 1 gate|up: 384 x 12288): the 128x128 engine would need a second, mostly
+    // empty round (288 tiles); the 192x96 / 96x192 tiles give every CU exactly one (27 vs 34 us, profiles/r03_b1_bench.txt)
+    const long t0 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (!a.m_count && t0 > 256 && fill(t0) < 0.75) {
+        const long tall = (long)((a.M + 191) / 192) * ((a.N + 95) / 96), wide = (long)((a.M + 95) / 96) * ((a.N + 191) / 192);
+        if (tall >= 200 && tall <= 256) return 12;
+        if (wide >= 200 && wide <= 256) return 10;
+    }
     return 0;
 }
 
@@ -1203,7 +1336,7 @@ static int launch(const GemmArgs& a, hipStream_t s) {
 extern "C" int coda_gemm_bf16_ex(const void* X, long long ldx, const int* x_rows, const void* W, long long ldw,
                                  void* C, long long ldc, const void* R, long long ldr,
                                  int M, int N, int K, int epilogue, int forced_engine, int flags, void* stream) {
-    if (forced_engine < 0 || forced_engine > 9) return CODA_ERR_ARG;
+    if (forced_engine < 0 || forced_engine > 12) return CODA_ERR_ARG;
     if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0 || N % 4 != 0) return CODA_ERR_SHAPE;
     if (epilogue == EPI_SWIGLU && N % 32 != 0) return CODA_ERR_SHAPE;
     if (epilogue == EPI_RESIDUAL && R == nullptr) return CODA_ERR_ARG;
@@ -1235,6 +1368,9 @@ extern "C" int coda_gemm_bf16_ex(const void* X, long long ldx, const int* x_rows
         case EPI_F32: return fn<EPI_F32>(a, s);                \
         default: return CODA_ERR_ARG;                          \
     }
+    if (engine == 12) { CODA_DISPATCH(launch192x96) }
+    if (engine == 11) { CODA_DISPATCH(launch128x192) }
+    if (engine == 10) { CODA_DISPATCH(launch96x192) }
     if (engine == 9) { CODA_DISPATCH(launch256w4_6) }
     if (engine == 8) { CODA_DISPATCH(launch256w4_8) }
     if (engine == 7) { CODA_DISPATCH(launch256px) }

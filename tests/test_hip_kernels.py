@@ -73,7 +73,7 @@ def test_gemm_exact_integer(M, N, K):
 
 
 @pytest.mark.parametrize("wide", [1, 0])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize("M,N,K,epi", [(512, 512, 64, "f32"), (768, 256, 192, "plain"), (300, 520, 128, "f32"),
                                        (1024, 768, 2048, "res"), (515, 512, 320, "res"), (8192, 5120, 128, "plain"),
                                        (8192 + 40, 4096 + 128, 64, "res")])
@@ -94,7 +94,7 @@ def test_gemm_engines_exact_integer(variant, M, N, K, epi, wide):
         assert torch.equal(gemm(X.to(DEV), W.to(DEV), _lib.EPI_RESIDUAL, R=R.to(DEV), engine=variant, flags=fl).cpu(), want)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_gemm_engines_swiglu(variant):
     from coda_amd.engine import interleave_gate_up
     M, I, K = 520, 384, 256
@@ -111,7 +111,7 @@ def test_gemm_engines_swiglu(variant):
 def test_gemm_ex_rejects_unknown_engine():
     X = torch.zeros(64, 64, device=DEV, dtype=BF)
     C = torch.zeros(64, 64, device=DEV, dtype=BF)
-    rc = _lib.load().coda_gemm_bf16_ex(_p(X), 64, None, _p(X), 64, _p(C), 64, None, 0, 64, 64, 64, 0, 12, 0, _s())
+    rc = _lib.load().coda_gemm_bf16_ex(_p(X), 64, None, _p(X), 64, _p(C), 64, None, 0, 64, 64, 64, 0, 13, 0, _s())
     assert rc == -4
 
 
