@@ -311,7 +311,7 @@ __device__ __forceinline__ void epilogue_tail2(const GemmArgs& a, const f32x4_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-// (32*MT)x192 engine (gemm_tile192.h): few token rows, one tile per CU, three ring stages.  No row gather, no device
+// 96x192 / 192x96 engine (gemm_tile192.h): few token rows, one tile per CU, three ring stages.  No row gather, no device
 // row count, no split-K.
 template <int EPI, int MT, int STAGES, bool TALL>
 __global__ __launch_bounds__(256, 2) void gemm192_bf16_kernel(GemmArgs a) {
@@ -343,7 +343,16 @@ __global__ __launch_bounds__(256, 2) void gemm192_bf16_kernel(GemmArgs a) {
         for (int i = 0; i < 2; ++i) tail[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
 
+#ifdef CODA_CLOCK_PROBE
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     T::mainloop(f, a.K, lds, wave, lane, acc, tail);
+#ifdef CODA_CLOCK_PROBE
+    if (a.probe && threadIdx.x == 0 && blockIdx.x < 256) {   // K loop only: shader cycles and 100 MHz ticks
+        a.probe[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - probe_t0;
+        a.probe[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
+    }
+#endif
 
     const bool full = m0 + T::BM <= a.M && n0 + T::BN <= a.N;
     const int mrow0 = m0 + wm * 16 * MT, ncol0 = n0 + wn * 96;
@@ -363,7 +372,6 @@ static int launch192(GemmArgs a, hipStream_t s) {
     return CODA_OK;
 }
 template <int EPI> static int launch96x192(GemmArgs a, hipStream_t s) { return launch192<EPI, 3>(a, s); }
-template <int EPI> static int launch128x192(GemmArgs a, hipStream_t s) { return launch192<EPI, 4>(a, s); }
 template <int EPI> static int launch192x96(GemmArgs a, hipStream_t s) { return launch192<EPI, 3, 3, true>(a, s); }
 
 // ---------------------------------------------------------------------------------------------
@@ -1292,7 +1300,8 @@ extern "C" int coda_gemm_probe(void* buf) {
 // `forced` (the engine argument of coda_gemm_bf16_ex): 0 automatic, 1 128x128, 2 256x256 (one tile per workgroup),
 // 3 persistent 256x256, 4 persistent 256x128, 5 persistent 192x256 (3-stage weight ring), 6 persistent 192x256 with the
 // 3-stage ring on the activations, 7 persistent 256x256 with a 3-stage activation ring (160 KiB of LDS),
-// 8 / 9 four-wave persistent 256x256 / 192x256 (wave tile 128 / 96 tokens x 128 features, one wave per SIMD).
+// 8 / 9 four-wave persistent 256x256 / 192x256 (wave tile 128 / 96 tokens x 128 features, one wave per SIMD),
+// 10 / 11 one 96x192 / 192x96 tile per CU for a few hundred rows (gemm_tile192.h).
 // -> 0: 128x128 engine, otherwise the engine number above.  The choice is a pure function of the call's arguments.
 static int pick_engine(const GemmArgs& a, int forced) {
     if (a.x_rows) return 0;
@@ -1319,7 +1328,7 @@ static int pick_engine(const GemmArgs& a, int forced) {
     const long t0 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (!a.m_count && t0 > 256 && fill(t0) < 0.75) {
         const long tall = (long)((a.M + 191) / 192) * ((a.N + 95) / 96), wide = (long)((a.M + 95) / 96) * ((a.N + 191) / 192);
-        if (tall >= 200 && tall <= 256) return 12;
+        if (tall >= 200 && tall <= 256) return 11;
         if (wide >= 200 && wide <= 256) return 10;
     }
     return 0;
@@ -1336,7 +1345,7 @@ static int launch(const GemmArgs& a, hipStream_t s) {
 extern "C" int coda_gemm_bf16_ex(const void* X, long long ldx, const int* x_rows, const void* W, long long ldw,
                                  void* C, long long ldc, const void* R, long long ldr,
                                  int M, int N, int K, int epilogue, int forced_engine, int flags, void* stream) {
-    if (forced_engine < 0 || forced_engine > 12) return CODA_ERR_ARG;
+    if (forced_engine < 0 || forced_engine > 11) return CODA_ERR_ARG;
     if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0 || N % 4 != 0) return CODA_ERR_SHAPE;
     if (epilogue == EPI_SWIGLU && N % 32 != 0) return CODA_ERR_SHAPE;
     if (epilogue == EPI_RESIDUAL && R == nullptr) return CODA_ERR_ARG;
@@ -1368,8 +1377,7 @@ extern "C" int coda_gemm_bf16_ex(const void* X, long long ldx, const int* x_rows
         case EPI_F32: return fn<EPI_F32>(a, s);                \
         default: return CODA_ERR_ARG;                          \
     }
-    if (engine == 12) { CODA_DISPATCH(launch192x96) }
-    if (engine == 11) { CODA_DISPATCH(launch128x192) }
+    if (engine == 11) { CODA_DISPATCH(launch192x96) }
     if (engine == 10) { CODA_DISPATCH(launch96x192) }
     if (engine == 9) { CODA_DISPATCH(launch256w4_6) }
     if (engine == 8) { CODA_DISPATCH(launch256w4_8) }

@@ -1,4 +1,4 @@
-// (32*MT)x192x64 bf16 MFMA tile engine with a three-stage LDS ring, for projections with FEW token rows and many
+// 96x192x64 / 192x96x64 bf16 MFMA tile engine with a three-stage LDS ring, for projections with FEW token rows and many
 // features (the B = 1 decoder: 384 tokens x 12288 gate|up features).
 //
 // Why another tile shape: with a few hundred rows a launch has about as many tiles as the chip has CUs, one workgroup
@@ -15,13 +15,16 @@
 // wm*16*MT.., features wn*96..: 6 x MT accumulator tiles, kept as a 4 x MT block and a 2 x MT block so the shared
 // epilogues (four feature blocks per call) serve the first and a two-block tail serves the second.
 #pragma once
+#include <type_traits>
+
 #include "coda_common.h"
 
 namespace tile192 {
 
 constexpr int BK = 64;
 
-// TALL = false: waves as 2 x 2, tile (32*MT) x 192.  TALL = true: waves as 4 x 1, tile (64*MT) x 96 - the same wave
+// TALL = false: waves as 2 x 2, tile (32*MT) x 192.  TALL = true: waves as 4 x 1, tile (64*MT) x 96 (MT = 3 is what is
+// instantiated; MT = 4 compiles, but its 96 accumulators + 20 fragment registers spill at 256 VGPRs) - the same wave
 // tile, but the workgroup pulls twice the activation rows (L2 hits: every workgroup of the launch reads them) and
 // half the weight rows (misses: a weight row is new to the chip when its first reader asks for it, and readers of
 // the same row in other CUs wait on that same miss).  A CU's load path sustains 66-73 GB/s on L2 hits but 24-33 GB/s
@@ -92,16 +95,32 @@ struct Tile {
                            "+v"(g.x[1]), "+v"(g.x[2]), "+v"(g.x[3]));
     }
 
-    static __device__ __forceinline__ void mma(const Frags& g, f32x4_t (&acc)[4][MT], f32x4_t (&tail)[2][MT]) {
+    // one LDS-DMA instruction of a stage: pieces 0..XI-1 are activation rows, XI..DMA_PER_STAGE-1 weight rows
+    template <int J>
+    static __device__ __forceinline__ void piece(const Src& f, size_t kbyte, char* lds_stage, int wave) {
+        if constexpr (J < XI) glds16(f.x[J] + kbyte, lds_stage + (J * 4 + wave) * 1024);
+        else glds16(f.w[J - XI] + kbyte, lds_stage + X_BYTES + ((J - XI) * 4 + wave) * 1024);
+    }
+
+    // The MFMAs of one K step in six groups (one weight fragment each); with DMA, group g is preceded by piece J0 + g
+    // of the stage being refilled.  All four waves issuing a whole stage back to back right after the barrier kept
+    // every wave in the CU's address path (one 1-KiB piece per ~16 cycles) with its MFMA pipe idle - one wave per
+    // SIMD, nobody to cover; spread out, a piece is accepted while the group before it is still in the pipe.
+    template <bool DMA, int J0>
+    static __device__ __forceinline__ void mma(const Frags& g, f32x4_t (&acc)[4][MT], f32x4_t (&tail)[2][MT], const Src& f,
+                                               size_t kbyte, char* lds_stage, int wave) {
+        auto group = [&](auto NT) {
+            constexpr int nt = decltype(NT)::value;
+            if constexpr (DMA && J0 + nt < DMA_PER_STAGE) piece<J0 + nt>(f, kbyte, lds_stage, wave);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g.w[nt], g.x[mt], acc[nt][mt], 0, 0, 0);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                tail[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g.w[4 + nt], g.x[mt], tail[nt][mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) {
+                if constexpr (nt < 4) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g.w[nt], g.x[mt], acc[nt][mt], 0, 0, 0);
+                else tail[nt - 4][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g.w[nt], g.x[mt], tail[nt - 4][mt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 1>{}); group(std::integral_constant<int, 2>{});
+        group(std::integral_constant<int, 3>{}); group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{});
     }
 
     // s_waitcnt vmcnt(N tiles' worth of this wave's DMAs) lgkmcnt(0).
@@ -116,12 +135,14 @@ struct Tile {
     // K loop of one tile, software-pipelined inside the wave: with one wave per SIMD nobody else covers a wave's LDS
     // reads, so the fragments of K step s+1 are requested BEFORE the MFMAs of step s are issued (measured without this:
     // 0.64 us per K tile for 0.24 us of MFMA).  A K tile is two steps; iteration t:
-    //     request step (t,1) | MFMAs of (t,0) | wait: own reads done, tile t+1 landed (tile t+2 may stay in flight) |
-    //     barrier: tile t+1 is complete and NOBODY reads tile t's buffer any more | DMA of tile t+3 into that buffer |
-    //     request step (t+1,0) | MFMAs of (t,1)
-    // so three ring stages keep up to three tiles in flight.  (A plain __syncthreads() would drain vmcnt to 0: its
-    // fence covers the DMA.)
-    // (T192_NO_DMA / T192_NO_COMPUTE: diagnostic builds that time the two halves of the loop alone.)
+    //     request step (t,1) | MFMAs of (t,0) [+ the last pieces of tile t+2] | wait: own reads done, tile t+1 landed
+    //     (tile t+2 may stay in flight) | barrier: tile t+1 is complete and NOBODY reads tile t's buffer any more |
+    //     request step (t+1,0) | MFMAs of (t,1) [+ the first six pieces of tile t+3, into tile t's buffer]
+    // so three ring stages keep up to three tiles in flight.  A stage's pieces are all issued before the wait that
+    // counts them (six behind the barrier of iteration t-1, the rest ahead of the wait of iteration t), so the wait
+    // immediates do not depend on where the pieces stand.  (A plain __syncthreads() would drain vmcnt to 0: its fence
+    // covers the DMA.)  The first iteration and the last three have no (or only half of the) DMA: separate
+    // instances of the body, no branch inside it.
     static __device__ __forceinline__ void mainloop(const Src& f, int K, char* lds, int wave, int lane, f32x4_t (&acc)[4][MT],
                                                     f32x4_t (&tail)[2][MT]) {
         static_assert(STAGES == 3, "the wait immediates below assume three stages");
@@ -137,25 +158,31 @@ struct Tile {
         Frags ga, gb;
         read(lds, 0, wm, wn, lane, ga);
         int cur = 0;                              // ring position of tile t
-        for (int t = 0; t < nk; ++t) {
-            const int nx = cur == 2 ? 0 : cur + 1;
+        // DA: the tail pieces of tile t+2 go out under step (t,0); DB: the first six pieces of tile t+3 under step (t,1)
+        auto iteration = [&](int t, auto DA_, auto DB_) {
+            constexpr bool DA = decltype(DA_)::value, DB = decltype(DB_)::value;
+            const int nx = cur == 2 ? 0 : cur + 1, pv = cur == 0 ? 2 : cur - 1;
             read(lds + cur * STAGE_BYTES, 1, wm, wn, lane, gb);
             landed(ga);
-#ifndef T192_NO_COMPUTE
-            mma(ga, acc, tail);
-#endif
+            mma<DA, 6>(ga, acc, tail, f, (size_t)(t + 2) * BK * 2, lds + pv * STAGE_BYTES, wave);
             if (t + 2 < nk) wait_all_but<1>();
             else wait_all_but<0>();
             __builtin_amdgcn_s_barrier();
-#ifndef T192_NO_DMA
-            if (t + 3 < nk) stage(f, (size_t)(t + 3) * BK * 2, lds + cur * STAGE_BYTES, wave);
-#endif
             if (t + 1 < nk) read(lds + nx * STAGE_BYTES, 0, wm, wn, lane, ga);   // (never leave a request in flight at the
             landed(gb);                                                          //  end: its registers get reused)
-#ifndef T192_NO_COMPUTE
-            mma(gb, acc, tail);
-#endif
+            mma<DB, 0>(gb, acc, tail, f, (size_t)(t + 3) * BK * 2, lds + cur * STAGE_BYTES, wave);
             cur = nx;
+        };
+        using Y = std::true_type;
+        using N = std::false_type;
+        if (nk >= 4) {
+            iteration(0, N{}, Y{});
+            for (int t = 1; t + 3 < nk; ++t) iteration(t, Y{}, Y{});
+            iteration(nk - 3, Y{}, N{});
+            iteration(nk - 2, N{}, N{});
+            iteration(nk - 1, N{}, N{});
+        } else {
+            for (int t = 0; t < nk; ++t) iteration(t, N{}, N{});
         }
     }
 };
