@@ -1616,6 +1616,75 @@ __global__ __launch_bounds__(64) void splitk_residual_rmsnorm_kernel(const float
     }
 }
 
+// The same for rows of at most 2048 features (the decoder's hidden size), with a WORKGROUP per row: 384 lone waves that
+// each stream 64 KB of partial tiles left three quarters of the chip's wave slots empty (7.9 us for 25 MB).  Thread t owns
+// piece t; all eight slabs' loads of a piece are in flight at once; the sum of squares is then formed by wave 0 from an
+// LDS copy of the row in exactly the order of the one-wave kernel (lane l: pieces l, l + 64, l + 128, l + 192 in sequence,
+// then the butterfly), so the two kernels - and rmsnorm_kernel behind splitk_epilogue_kernel - agree bit for bit.
+__global__ __launch_bounds__(256) void splitk_residual_rmsnorm_row256_kernel(const float* __restrict__ part, long long slab_floats,
+                                                                            int ksplit, int M, int N, char* __restrict__ C,
+                                                                            long long ldc_bytes, const char* __restrict__ R,
+                                                                            long long ldr_bytes, const u32x4_t* __restrict__ nw,
+                                                                            char* __restrict__ normed, long long ldn_bytes, float eps) {
+    __shared__ u32x4_t vrow[256];
+    __shared__ float s_inv;
+    const int tid = threadIdx.x, row = blockIdx.x;
+    const int chunks = N / 8;
+    const bool on = tid < chunks;
+    const int c = on ? tid : 0;                       // idle threads re-read piece 0 of this row (always in bounds)
+    const float* prow = part + (size_t)row * N + (size_t)c * 8;
+    const u32x4_t r = *(const u32x4_t*)(R + (size_t)row * ldr_bytes + (size_t)c * 16);
+    f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < ksplit; s0 += 8) {
+        f32x4_t a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* p = prow + (size_t)(s0 + u < ksplit ? s0 + u : s0) * slab_floats;
+            a[u] = *(const f32x4_t*)p;
+            b[u] = *(const f32x4_t*)(p + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (s0 + u < ksplit) {
+                lo += a[u];
+                hi += b[u];
+            }
+    }
+    u32x4_t v = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = pack_bf16x2(bf16_lo(v[j]) + bf16_lo(r[j]), bf16_hi(v[j]) + bf16_hi(r[j]));
+    if (on) *(u32x4_t*)(C + (size_t)row * ldc_bytes + (size_t)c * 16) = v;
+    vrow[tid] = v;
+    __syncthreads();
+    if (tid < 64) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ci = tid + 64 * i;
+            if (ci < chunks) {
+                float f[8];
+                unpack8(vrow[ci], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+            }
+        }
+        ss = wave_sum(ss);
+        if (tid == 0) s_inv = 1.0f / sqrtf(ss / (float)N + eps);
+    }
+    __syncthreads();
+    if (on) {
+        const float inv = s_inv;
+        float f[8], g[8];
+        unpack8(v, f);
+        unpack8(nw[c], g);
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = pack_bf16x2(g[2 * j] * round_bf16(f[2 * j] * inv), g[2 * j + 1] * round_bf16(f[2 * j + 1] * inv));
+        *(u32x4_t*)(normed + (size_t)row * ldn_bytes + (size_t)c * 16) = o;
+    }
+}
+
 // q/k/v projection (modeling_coda.py:123-125), then q_norm / k_norm + rotary (:128-148, modeling_utils.py:70-101) on the q
 // and k heads; v heads are only rounded.  16 lanes per (token, head) row of 128 features, as qknorm_rope_kernel.
 __global__ __launch_bounds__(256) void splitk_qknorm_rope_kernel(const float* __restrict__ part, long long slab_floats, int ksplit,
@@ -1631,10 +1700,23 @@ __global__ __launch_bounds__(256) void splitk_qknorm_rope_kernel(const float* __
     const long long rr = live ? row : total - 1;            // keep all lanes in the shuffles
     const int t = (int)(rr / n_heads), h = (int)(rr % n_heads);
     f32x4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < ksplit; ++s) {
-        const float* p = part + (size_t)s * slab_floats + (size_t)t * N + h * 128 + sub * 8;
-        lo += *(const f32x4_t*)p;
-        hi += *(const f32x4_t*)(p + 4);
+    // ascending slab order per element, up to eight slabs' loads in flight (a loop of load - add - load serialises the
+    // latencies: the trip count is a run-time value, the compiler does not batch the loads by itself)
+    const float* p0 = part + (size_t)t * N + h * 128 + sub * 8;
+    for (int s0 = 0; s0 < ksplit; s0 += 8) {
+        f32x4_t a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* p = p0 + (size_t)(s0 + u < ksplit ? s0 + u : s0) * slab_floats;
+            a[u] = *(const f32x4_t*)p;
+            b[u] = *(const f32x4_t*)(p + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (s0 + u < ksplit) {
+                lo += a[u];
+                hi += b[u];
+            }
     }
     const u32x4_t v = {pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
     u32x4_t* out = (u32x4_t*)(qkv + (size_t)t * ld_b + (size_t)h * 256) + sub;
@@ -1699,7 +1781,10 @@ extern "C" int coda_gemm_bf16_splitk_norm(const void* X, long long ldx, const vo
     if (rc != CODA_OK) return rc;
     const float* part = (const float*)workspace;
     const long long slab = (long long)M * N;
-    if (N <= 4 * 64 * 8)
+    if (N <= 256 * 8)
+        hipLaunchKernelGGL(splitk_residual_rmsnorm_row256_kernel, dim3(M), dim3(256), 0, s, part, slab, ksplit, M, N, (char*)C, ldc * 2,
+                           (const char*)R, ldr * 2, (const u32x4_t*)norm_weight, (char*)normed, ld_normed * 2, eps);
+    else if (N <= 4 * 64 * 8)
         hipLaunchKernelGGL(splitk_residual_rmsnorm_kernel<4>, dim3(M), dim3(64), 0, s, part, slab, ksplit, M, N, (char*)C, ldc * 2,
                            (const char*)R, ldr * 2, (const u32x4_t*)norm_weight, (char*)normed, ld_normed * 2, eps);
     else
