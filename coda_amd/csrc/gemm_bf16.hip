@@ -323,9 +323,18 @@ __global__ __launch_bounds__(256, 2) void gemm192_bf16_kernel(GemmArgs a) {
     // consecutive ids walk the row tiles of one feature panel, an XCD's chunk of ids covers whole panels:
     // every weight panel is fetched from HBM by one XCD only, the (small) activation matrix lives in every L2
     const int ntile = a.tiles_m * a.tiles_n;
-    const int id = xcd_remap(blockIdx.x, ntile);
+    int id = xcd_remap(blockIdx.x, ntile * a.ksplit);
+    // split-K (EPI_F32 only): K range ks of tile id writes its fp32 partial tile to slab ks; the ranges of a tile are
+    // neighbours in the id order
+    const int ks = id % a.ksplit;
+    id /= a.ksplit;
     const int tm = id % a.tiles_m, tn = id / a.tiles_m;
     const int m0 = tm * T::BM, n0 = tn * T::BN;
+    const int kc = a.K / a.ksplit;            // host guarantees kc % BK == 0
+    a.X += (size_t)ks * kc * 2;
+    a.W += (size_t)ks * kc * 2;
+    a.C += (size_t)ks * a.slab_bytes;
+    a.K = kc;
 
     typename T::Src f;
     const int ch = T::dma_chunk(lane) * 16;
@@ -367,7 +376,7 @@ static int launch192(GemmArgs a, hipStream_t s) {
     if (coda_ensure_dyn_lds((const void*)gemm192_bf16_kernel<EPI, MT, STAGES, TALL>, T::LDS_BYTES) != CODA_OK) return CODA_ERR_LAUNCH;
     a.tiles_m = (a.M + T::BM - 1) / T::BM;
     a.tiles_n = (a.N + T::BN - 1) / T::BN;
-    hipLaunchKernelGGL((gemm192_bf16_kernel<EPI, MT, STAGES, TALL>), dim3(a.tiles_m * a.tiles_n), dim3(256), T::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm192_bf16_kernel<EPI, MT, STAGES, TALL>), dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(256), T::LDS_BYTES, s, a);
     CODA_CHECK_LAUNCH("gemm192_bf16");
     return CODA_OK;
 }
@@ -1749,6 +1758,17 @@ __global__ __launch_bounds__(256) void splitk_qknorm_rope_kernel(const float* __
     if (live) *out = h < n_qk ? o : v;
 }
 
+// Which engine writes the partial tiles - a pure function of the call's (M, N, ksplit).  When the 192x96 tiles times the K
+// ranges fit ONE workgroup per CU, that engine takes them (three-stage ring, 81 vs ~40 GB/s per CU through the load path
+// at one workgroup per CU: profiles/r03b_t192_probe.txt); otherwise the 128x128 engine with up to two workgroups per CU.
+// Every engine sums a K range in the same order, so the choice does not change a bit of the result
+// (test_gemm_few_rows_picker_takes_the_one_tile_per_cu_engine, test_gemm_splitk_exact_integer).
+static int launch_splitk_partials(const GemmArgs& a, hipStream_t s) {
+    const long wgs = (long)((a.M + 191) / 192) * ((a.N + 95) / 96) * a.ksplit;
+    if (a.M > 128 && wgs >= 128 && wgs <= 256) return launch192x96<EPI_F32>(a, s);
+    return launch<EPI_F32>(a, s);
+}
+
 // shared front half of the split-K entry points: argument checks + the partial-tile GEMM into the workspace
 static int splitk_partials(const void* X, long long ldx, const void* W, long long ldw, int M, int N, int K, int ksplit,
                            void* workspace, long long workspace_bytes, hipStream_t s) {
@@ -1764,7 +1784,7 @@ static int splitk_partials(const void* X, long long ldx, const void* W, long lon
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
     a.wide = 0;
     a.ksplit = ksplit; a.slab_bytes = (long long)M * N * 4;
-    return launch<EPI_F32>(a, s);
+    return launch_splitk_partials(a, s);
 }
 
 extern "C" int coda_gemm_bf16_splitk_norm(const void* X, long long ldx, const void* W, long long ldw, void* C, long long ldc,
@@ -1834,7 +1854,7 @@ extern "C" int coda_gemm_bf16_splitk(const void* X, long long ldx, const void* W
     a.wide = 0;
     a.ksplit = ksplit; a.slab_bytes = (long long)M * N * 4;
     hipStream_t s = (hipStream_t)stream;
-    const int rc = launch<EPI_F32>(a, s);
+    const int rc = launch_splitk_partials(a, s);
     if (rc != CODA_OK) return rc;
     const long long threads = (long long)M * ((epilogue == EPI_SWIGLU ? N / 2 : N) / 4);
     const dim3 grid((unsigned)((threads + 255) / 256));

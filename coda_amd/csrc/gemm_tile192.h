@@ -3,7 +3,7 @@
 //
 // Why another tile shape: with a few hundred rows a launch has about as many tiles as the chip has CUs, one workgroup
 // per CU, and the time of the launch is the time ONE CU needs to pull its tile's operand panels through its LDS-DMA
-// path (about 50-64 GB/s per CU, profiles/r03_b1_bench.txt) - not HBM, not MFMA.  Two things then matter:
+// path (56-60 GB/s per CU with every CU pulling, 81 on an idle chip: profiles/r03b_t192_probe.txt) - not HBM, not MFMA.  Two things then matter:
 //   * every CU gets exactly one tile (the 128x128 engine makes 288 tiles of 384 x 12288: 32 CUs do two), and the tile
 //     is as square as that allows (bytes pulled per CU = (BM + BN) * K * 2);
 //   * the single workgroup of a CU keeps more than one K tile in flight: three ring stages and a counted vmcnt
@@ -13,7 +13,8 @@
 // Operand convention, LDS image and swizzle are those of gemm_tile128.h (weights as MFMA operand A, lane-linear DMA
 // destination with the XOR applied on the source address).  Four waves as 2 x 2: wave (wm, wn) owns tokens
 // wm*16*MT.., features wn*96..: 6 x MT accumulator tiles, kept as a 4 x MT block and a 2 x MT block so the shared
-// epilogues (four feature blocks per call) serve the first and a two-block tail serves the second.
+// epilogues (four feature blocks per call) serve the first and a two-block tail serves the second.  With ksplit > 1
+// (fp32 partial tiles, split-K path) a workgroup takes one K range of its tile.
 #pragma once
 #include <type_traits>
 

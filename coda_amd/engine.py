@@ -62,6 +62,9 @@ def permute_qk_rows(wqkv: torch.Tensor, n_q: int, n_kv: int, d: int = 128) -> to
 SPLITK_WS_BYTES = 32 << 20
 
 
+SPLITK_OVERRIDE: Dict[tuple, int] = {}
+
+
 def splitk_factor(M: int, N: int, K: int, ws_bytes: int = SPLITK_WS_BYTES) -> int:
     """K ranges for a projection at small M (coda_gemm_bf16_splitk).  A launch with fewer than ~160 tiles of 128 x 128 leaves
     most CUs without work while the busy ones are bound by their own 64 B/clk load path; cutting K engages up to ~450
@@ -69,6 +72,18 @@ def splitk_factor(M: int, N: int, K: int, ws_bytes: int = SPLITK_WS_BYTES) -> in
     tiles = -(-M // 128) * -(-N // 128)
     if tiles >= 160 or M > 1024:          # measured at M = 384: gate|up (288 tiles) in two ranges is a loss (4.40 vs 3.81 ms per step)
         return 1
+    if (M, N, K) in SPLITK_OVERRIDE:      # tools only (tools/b1_bench.py sweeps): never set by the product path
+        return SPLITK_OVERRIDE[(M, N, K)]
+    # 257..384 rows (B = 1 at 128 + 256 tokens): when 192 x 96 tiles x ranges fit one workgroup per CU the library writes the
+    # partial tiles with its three-stage engine (launch_splitk_partials in gemm_bf16.hip: the same function of M, N, ranges),
+    # which needs half the ranges - half the fp32 partial traffic - for the same time in the K loop.  Measured per denoise
+    # step (tools/splitk_sweep.sh): o_proj 8 -> 4 ranges 3.27 -> 3.20 ms, qkv 4 -> 2 3.20 -> 3.18; down 8 -> 4 is a loss
+    # (3.19: 24 K tiles per workgroup), hence the bound on the range length
+    if 256 < M <= 384:
+        tall = 2 * -(-N // 96)
+        for s in range(256 // tall, 1, -1):
+            if tall * s >= 128 and K % s == 0 and (K // s) % 64 == 0 and K // s <= 1024 and s * M * N * 4 <= ws_bytes:
+                return s
     best = 1
     for s in range(2, max(1, 448 // tiles) + 1):
         if K % s == 0 and (K // s) % 64 == 0 and K // s >= 256 and s * M * N * 4 <= ws_bytes:

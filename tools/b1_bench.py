@@ -21,6 +21,12 @@ model.eval()
 with torch.no_grad():
     model.lm_head.weight.mul_(8.0)
 eng = model.hip_engine()
+if os.environ.get("SPLITK"):      # e.g. SPLITK="2048:2048:4,4096:2048:2,2048:6144:4" = N:K:ranges at M = 384 (and the 32-row compact tail follows)
+    from coda_amd import engine as _engine
+    for item in os.environ["SPLITK"].split(","):
+        n_, k_, s_ = (int(v) for v in item.split(":"))
+        _engine.SPLITK_OVERRIDE[(384, n_, k_)] = s_
+    print("split-K override:", _engine.SPLITK_OVERRIDE, flush=True)
 ids = torch.randint(0, 151643, (1, 128), device=dev)
 cases = [("C1 (block 32, greedy)", dict(alg="entropy", block_length=32)),
          ("serving defaults (alg_temp 0.1, no window)", dict(alg="entropy", alg_temp=0.1))]
