@@ -57,8 +57,21 @@ __device__ __forceinline__ int widen16_offset(int lane) {
 // matrix (no bounds tests); FULL tiles of 16-byte aligned matrices (a.wide) go out as 16-byte pieces (widen16).
 // Rounding points follow the reference's bf16 op sequence: the projection
 // output is rounded first, then residual add / silu / gate*up each round again.
-template <int EPI, int MT, bool FULL>
-__device__ __forceinline__ void epilogue_wave(const GemmArgs& a, const f32x4_t (&acc)[4][MT], int mrow0, int ncol0, int lane) {
+// residual values of a wave tile in the widened layout, fetched by the caller ahead of the epilogue (residual_prefetch)
+template <int MT>
+struct ResidualTile { u32x4_t v[MT][2]; };
+
+// token group mt of the wave tile: the two 16-byte residual pieces the widened RESIDUAL epilogue adds to it
+template <int MT>
+__device__ __forceinline__ void residual_prefetch(const GemmArgs& a, ResidualTile<MT>& rt, int mt, int mrow0, int ncol0, int lane) {
+    const char* r = a.R + (size_t)(mrow0 + (lane & 15) + mt * 16) * a.ldr_bytes + (size_t)ncol0 * 2 + widen16_offset(lane);
+    rt.v[mt][0] = *(const u32x4_t*)r;
+    rt.v[mt][1] = *(const u32x4_t*)(r + 64);
+}
+
+template <int EPI, int MT, bool FULL, bool PRE = false>
+__device__ __forceinline__ void epilogue_wave(const GemmArgs& a, const f32x4_t (&acc)[4][MT], int mrow0, int ncol0, int lane,
+                                              const ResidualTile<MT>* pre = nullptr) {
     const int tok = lane & 15, fq = (lane >> 4) * 4;
     const int mf = mrow0 + tok;
     const size_t rs = (size_t)16 * a.ldc_bytes;
@@ -115,7 +128,12 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, const f32x4_t (
 #pragma unroll
             for (int mb = 0; mb < MT; mb += MB) {
                 u32x4_t rv[MB][2];
-                if constexpr (EPI == EPI_RESIDUAL) {
+                if constexpr (EPI == EPI_RESIDUAL && PRE) {
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) rv[i][q] = pre->v[mb + i][q];
+                } else if constexpr (EPI == EPI_RESIDUAL) {
                     const char* r = a.R + (size_t)mf * a.ldr_bytes + (size_t)ncol0 * 2 + wo;
                     const size_t rrs = (size_t)16 * a.ldr_bytes;
 #pragma unroll
@@ -720,14 +738,31 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
     int pend_x = 0, pend_w = 0;
     int xcur = 0, wcur = 0;                   // byte offsets of the ring stages holding the current K tile
     int stores_in_flight = 0;                 // stores of the previous tile's epilogue if it was the unconditional (full-tile) one
+    // RESIDUAL on the 192-token tile (o_proj / down_proj: 2 rounds of 256 workgroups in lockstep): the residual tile is
+    // fetched DURING the last K tiles, one token group per K tile, instead of at the head of the epilogue, where all 256
+    // workgroups asked for their 98 KB at the same moment with the MFMA pipes idle (o_proj: 101 us with the residual
+    // epilogue against 85 plain).  The loads stand in front of their K tile's DMA, so the K-tile waits (which let only what
+    // is YOUNGER than the DMA stay in flight) cover them without a change.  48 registers (180 -> 228 of 256).
+    constexpr bool RPF = EPI == EPI_RESIDUAL && MTH == 3;
+    ResidualTile<T::MT> rtile;
     for (; Lc < ntiles; Lc += G) {
         coords(Lc, cm0, cn0);
+        const bool full = cm0 + T::BM <= a.M && cn0 + T::BN <= a.N;
+        const bool rpf = RPF && full && a.wide && nk >= T::MT;
         f32x4_t acc[4][T::MT];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < T::MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         for (int t = 0; t < nk; ++t) {
+            if constexpr (RPF) {
+                if (rpf && t >= nk - T::MT) {
+                    const int g = t - (nk - T::MT);          // wave-uniform; the switch keeps the register index static
+#pragma unroll
+                    for (int mt = 0; mt < T::MT; ++mt)
+                        if (g == mt) residual_prefetch<T::MT>(a, rtile, mt, cm0 + wm * (T::BM / 2), cn0 + wn * 64, lane);
+                }
+            }
             const int xnxt = xcur == (XST - 1) * T::X_BYTES ? 0 : xcur + T::X_BYTES;
             const int wnxt = wcur == (WST - 1) * T::W_BYTES ? 0 : wcur + T::W_BYTES;
             const char* xc = xs + xcur;
@@ -806,13 +841,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_kernel(GemmArgs a) {
             xcur = xnxt;
             wcur = wnxt;
         }
-        const bool full = cm0 + T::BM <= a.M && cn0 + T::BN <= a.N;
 #ifdef CODA_DIAG_NO_EPI                          // diagnostic builds only: the epilogue never runs (the test keeps the accumulators alive)
         if (__builtin_amdgcn_readfirstlane(__float_as_int(acc[0][0][0])) == 0x12345678) {
 #else
         {
 #endif
             if constexpr (EPI == EPI_QKROPE) epilogue256_qkrope(a, acc, cm0, cn0, wm, wn, wave, lane, (float*)(lds + PL::BYTES), full);
+            else if (RPF && rpf) epilogue_wave<EPI, T::MT, true, RPF>(a, acc, cm0 + wm * (T::BM / 2), cn0 + wn * 64, lane, &rtile);
             else epilogue_tile<EPI, T::MT>(a, acc, cm0 + wm * (T::BM / 2), cn0 + wn * 64, lane, full);
         }
         stores_in_flight = full ? (a.wide && EPI != EPI_F32 ? ST_WIDE : ST_NARROW) : 0;
