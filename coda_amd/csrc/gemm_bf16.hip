@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
         f.x[i] = a.X + (size_t)gm * a.ldx_bytes + ch;
         f.w[i] = a.W + (size_t)gn * a.ldw_bytes + ch;
     }
+    f.xlive = dma_live_mask(m0, a.M, __builtin_amdgcn_readfirstlane(wave));
 
     f32x4_t acc[4][4];
 #pragma unroll

@@ -27,7 +27,20 @@ struct Frag {
     // already offset to this lane's (row, swizzled chunk); advance by k0*2 bytes per K tile
     const char* x[4];
     const char* w[4];
+    // bit i: DMA instruction i of the ACTIVATION tile carries rows of the problem (wave-uniform).  A tile that sticks out
+    // of a short matrix (32 candidate rows in a 128-row tile) would otherwise re-read its last row 96 times per K tile
+    // through the CU's load path - the path these small-M launches are bound by; the rows it leaves stale in LDS only
+    // feed accumulator rows nobody reads
+    unsigned xlive = 0xfu;
 };
+
+// xlive of a tile whose first row is row0 in a matrix of `rows` rows
+__device__ __forceinline__ unsigned dma_live_mask(int row0, int rows, int wave) {
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m |= (row0 + (i * 4 + wave) * 8 < rows ? 1u : 0u) << i;
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+}
 
 // row_of(i): tile-local row handled by this lane in DMA instruction i (4 waves x 4 instr x 8 rows)
 __device__ __forceinline__ int dma_row(int i, int wave, int lane) { return (i * 4 + wave) * 8 + (lane >> 3); }
@@ -35,7 +48,8 @@ __device__ __forceinline__ int dma_chunk(int lane) { return (lane & 7) ^ (lane >
 
 __device__ __forceinline__ void stage(const Frag& f, size_t kbyte, char* lds_stage, int wave) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(f.x[i] + kbyte, lds_stage + (i * 4 + wave) * 1024);
+    for (int i = 0; i < 4; ++i)
+        if (f.xlive >> i & 1) glds16(f.x[i] + kbyte, lds_stage + (i * 4 + wave) * 1024);
 #pragma unroll
     for (int i = 0; i < 4; ++i) glds16(f.w[i] + kbyte, lds_stage + TILE_BYTES + (i * 4 + wave) * 1024);
 }

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void lmhead_partial_kernel(LmArgs a) {
             const int cand = min(rb * BM + dma_row(i, wave, lane), n - 1);
             f.x[i] = a.hidden + (size_t)a.src_rows[cand] * a.ldh_b + ch;
         }
+        f.xlive = dma_live_mask(rb * BM, n, __builtin_amdgcn_readfirstlane(wave));
         Stat st[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) st[mt] = stat_init();
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(256) void lmhead_partial_kernel(LmArgs a) {
 
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
+                if (rb * BM + wm * 64 + mt * 16 >= n) continue;      // token group beyond the candidate list (wave-uniform)
                 Stat s = st[mt];
                 const int cand = rb * BM + wm * 64 + mt * 16 + tok;
                 float l[16];
