@@ -170,7 +170,7 @@ def test_gemm_splitk_exact_integer(M, N, K, ks, epi):
     assert lib.coda_gemm_bf16_splitk(_p(X), K, _p(W), K, _p(C), cols, _p(R), 0 if R is None else N, M, N, K, code, ks, _p(ws), 16, _s()) == -1
 
 
-@pytest.mark.parametrize("M,N,K,ks", [(384, 2048, 2048, 8), (384, 2048, 2048, 4), (384, 2048, 6144, 8), (32, 2048, 6144, 8), (77, 256, 512, 2), (5, 4096, 1024, 4)])
+@pytest.mark.parametrize("M,N,K,ks", [(384, 2048, 2048, 8), (384, 2048, 2048, 4), (384, 2048, 6144, 8), (40, 2048, 1536, 3), (16, 512, 3072, 12), (32, 2048, 6144, 8), (77, 256, 512, 2), (5, 4096, 1024, 4)])
 def test_splitk_residual_norm_equals_two_calls(M, N, K, ks):
     """coda_gemm_bf16_splitk_norm (B = 1 serving shape: o_proj / down_proj + residual + the RMSNorm that follows, one reduce
     launch): bit-identical to coda_gemm_bf16_splitk(RESIDUAL) + coda_rmsnorm on random-normal data, out of place and in
@@ -201,7 +201,7 @@ def test_splitk_residual_norm_equals_two_calls(M, N, K, ks):
     assert lib.coda_gemm_bf16_splitk_norm(_p(X), K, _p(W), K, _p(C1), N, _p(R), N, M, N, K, ks, _p(ws), 16, _p(nw), _p(A1), N, 1e-6, _s()) == -1
 
 
-@pytest.mark.parametrize("B,L,n_q,n_kv,K,ks", [(1, 384, 16, 8, 2048, 4), (1, 384, 16, 8, 2048, 2), (2, 50, 4, 2, 512, 2), (1, 33, 2, 1, 256, 2)])
+@pytest.mark.parametrize("B,L,n_q,n_kv,K,ks", [(1, 384, 16, 8, 2048, 4), (1, 384, 16, 8, 2048, 2), (1, 33, 2, 1, 3072, 12), (2, 50, 4, 2, 512, 2), (1, 33, 2, 1, 256, 2)])
 def test_splitk_qkv_rope_equals_two_calls(B, L, n_q, n_kv, K, ks):
     """coda_qkv_proj_rope_splitk: split-K q|k|v projection whose reduce kernel also applies q_norm / k_norm + rotary -
     bit-identical to coda_gemm_bf16_splitk(PLAIN) + coda_qknorm_rope."""
