@@ -127,6 +127,24 @@ def test_gemm_few_rows_picker_takes_the_one_tile_per_cu_engine(M):
     assert torch.equal(gemm(X, W, _lib.EPI_F32, engine=10), gemm(X, W, _lib.EPI_F32, engine=1))
 
 
+@pytest.mark.parametrize("engine", [5, 6, 8, 0])
+def test_gemm_residual_in_place_equals_out_of_place(engine):
+    """The decoder adds o_proj / down_proj into the residual stream IN PLACE (C aliases R).  The 192x256 engines fetch a
+    tile's residual values during the last K tiles of that tile (before any of its stores) - the aliased call must give
+    the out-of-place result bit for bit, on random data, full and ragged tiles alike."""
+    g = torch.Generator().manual_seed(91)
+    M, N, K = 1000, 768, 2048
+    X = torch.randn(M, K, generator=g).to(BF).to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.03).to(BF).to(DEV)
+    R = torch.randn(M, N, generator=g).to(BF).to(DEV)
+    want = gemm(X, W, _lib.EPI_RESIDUAL, R=R, engine=1)
+    assert torch.equal(gemm(X, W, _lib.EPI_RESIDUAL, R=R, engine=engine), want)
+    C = R.clone()
+    _lib.call("coda_gemm_bf16_ex", _p(X), K, None, _p(W), K, _p(C), N, _p(C), N, M, N, K, _lib.EPI_RESIDUAL, engine, 0, _s())
+    torch.cuda.synchronize()
+    assert torch.equal(C, want)
+
+
 def test_gemm_ex_rejects_unknown_engine():
     X = torch.zeros(64, 64, device=DEV, dtype=BF)
     C = torch.zeros(64, 64, device=DEV, dtype=BF)
