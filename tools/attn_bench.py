@@ -17,7 +17,8 @@ if os.environ.get("ALT_LIB"):                 # a diagnostic build of the librar
 _lib.load()
 splits = [0] + [int(v) for v in os.environ.get("QSPLITS", "").split(",") if v]
 KNOB = os.environ.get("KNOB", "qsplit")
-for B, L in ((32, 384), (64, 768), (8, 2048)):
+SHAPES = [tuple(int(v) for v in it.split("x")) for it in os.environ.get("SHAPES", "32x384,64x768,8x2048").split(",")]   # BxL
+for B, L in SHAPES:
     n_q, n_kv, d = 16, 8, 128
     T = B * L
     torch.manual_seed(0)
